@@ -1,0 +1,267 @@
+/*
+ * mcf_hip.h -- C ABI of libmcf_hip.so, the MI355X (gfx950) network-simplex pivot engine.
+ *
+ * Drop-in boundary.  All file:line citations are relative to the reference
+ * repository pdegenhardt/MinCostFlow; "NS.cs" = src/MinCostFlow.Core/Lemon/Algorithms/NetworkSimplex.cs,
+ * "BSPO.cs" = src/MinCostFlow.Core/Lemon/Algorithms/Internal/BlockSearchPivotOptimized.cs.
+ *
+ * Two layers are exported:
+ *
+ *  (1) mcf_engine_*  -- the device side of the seam `private interface IFindEnteringArc
+ *      { bool FindEnteringArc(); }` (NS.cs:1286-1289) plus UpdatePotentials (NS.cs:1185-1209).  The
+ *      SoA arc arrays (Source, Target, _cost, State) and the node potentials _pi live in HBM; the
+ *      host keeps the sequential pivot loop and the spanning tree.  This is what a C# host binds
+ *      with [DllImport("mcf_hip")] in place of OptimizedPivotWrapper (NS.cs:1671-1724); the stub is
+ *      in INTEGRATION.md.
+ *
+ *  (2) mcf_ns_*      -- a C++ restatement of the host side of NetworkSimplex (the public setters /
+ *      Solve() / getters of NS.cs:153-527 and the tree maintenance NS.cs:925-1183) that drives
+ *      the engine, so the path can be exercised end to end without a .NET toolchain.  Names and
+ *      argument meaning mirror the reference class.  There is NO CPU entering-arc search in this
+ *      library: mcf_ns_solve() fails with MCF_ERR_NO_DEVICE when no HIP device is usable.
+ *
+ * Conventions: every function returns 0 (MCF_OK) or a negative mcf_status; the message is available
+ * from mcf_last_error() (thread-local).  Nothing throws across the ABI.  Host arrays are borrowed
+ * for the duration of the call only.  One engine / one solver = one host thread at a time (the
+ * reference solver is single-threaded: docs/platform-architecture.md:126-130).
+ */
+#ifndef MCF_HIP_H
+#define MCF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCF_API __attribute__((visibility("default")))
+
+typedef enum mcf_status {
+    MCF_OK = 0,
+    MCF_ERR_INVALID = -1,     /* bad argument (ArgumentException in the reference) */
+    MCF_ERR_NO_DEVICE = -2,   /* no usable HIP device / HIP runtime failure at start-up */
+    MCF_ERR_HIP = -3,         /* a HIP call failed later on */
+    MCF_ERR_OVERFLOW = -4,    /* a value does not fit the engine's int_width (use 64) */
+    MCF_ERR_TIMEOUT = -5,     /* the device did not answer */
+    MCF_ERR_STATE = -6,       /* call out of order (InvalidOperationException in the reference) */
+    MCF_ERR_IO = -7,          /* file / parse error */
+    MCF_ERR_COMM = -8         /* RCCL failure */
+} mcf_status;
+
+/* Types/PivotRule.cs:7-41 (values kept) */
+typedef enum mcf_pivot_rule { MCF_RULE_FIRST_ELIGIBLE = 0, MCF_RULE_BEST_ELIGIBLE = 1, MCF_RULE_BLOCK_SEARCH = 2 } mcf_pivot_rule;
+/* Which of the reference's two implementations of a rule is reproduced:
+ * PLAIN = the nested classes of NS.cs:1292-1668; OPTIMIZED = BSPO.cs (EnableOptimizedPivot(true)). */
+typedef enum mcf_semantics { MCF_SEM_PLAIN = 1, MCF_SEM_OPTIMIZED = 2 } mcf_semantics;
+/* Types/SupplyType.cs */
+typedef enum mcf_supply_type { MCF_SUPPLY_GEQ = 0, MCF_SUPPLY_LEQ = 1 } mcf_supply_type;
+/* Types/SolverStatus.cs:7-34 (values kept) */
+typedef enum mcf_solver_status { MCF_NOT_SOLVED = 0, MCF_OPTIMAL = 1, MCF_INFEASIBLE = 2, MCF_UNBOUNDED = 3, MCF_UNBALANCED = 4 } mcf_solver_status;
+
+/* SpanningTree.cs:53-71 */
+#define MCF_STATE_UPPER (-1)
+#define MCF_STATE_TREE 0
+#define MCF_STATE_LOWER 1
+
+/* "no upper bound" for mcf_ns_set_arc_bounds (the reference's default capacity, NS.cs:127,616) */
+#define MCF_INF_CAP INT64_MAX
+
+MCF_API const char *mcf_last_error(void);
+MCF_API const char *mcf_version(void);
+/* number of visible HIP devices (0 when there is none or the runtime cannot start); never fails */
+MCF_API int mcf_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * (1) Engine: entering-arc search + potential update on the device
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct mcf_engine mcf_engine;
+
+typedef struct mcf_engine_desc {
+    int32_t node_count;       /* nodes INCLUDING the artificial root: NS.cs:137 (_nodeCount + 1) */
+    int32_t arc_capacity;     /* arcs the host arrays hold: NS.cs:130 (_arcCount + 2 * _nodeCount) */
+    int32_t search_arc_num;   /* arcs the pivot rules scan, [0, search_arc_num): NS.cs:722 */
+    int32_t int_width;        /* 32 or 64: width of cost / potential ON THE DEVICE (the ABI is always int64) */
+    int32_t rule;             /* mcf_pivot_rule */
+    int32_t semantics;        /* mcf_semantics */
+    int32_t block_size;       /* Block Search: 0 = the reference's default for the semantics
+                                 (BSPO.cs:27-28 / NS.cs:1304-1336 with the default OptimizationConfig) */
+    int32_t device;           /* HIP device ordinal */
+    /* arc shard owned by this engine, [shard_begin, shard_end) within [0, search_arc_num); 0,0 = all.
+     * A sharded engine answers for its shard only (mcf_engine_find_entering_local). */
+    int32_t shard_begin, shard_end;
+    int32_t scan_workgroups;  /* 0 = auto; otherwise the grid of the scan kernel */
+    int32_t flags;            /* MCF_ENGINE_* */
+} mcf_engine_desc;
+
+#define MCF_ENGINE_SAMPLE_KERNEL_TIME 1   /* time every 16th scan dispatch with HIP events */
+#define MCF_ENGINE_TIME_EVERY_KERNEL 2    /* time every scan dispatch (micro-benchmarks) */
+#define MCF_ENGINE_NO_INLINE_UPDATE 4     /* always apply patches with the separate update kernel */
+
+/* replaces the constructor of OptimizedPivotWrapper (NS.cs:1677-1697) */
+MCF_API int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc);
+MCF_API void mcf_engine_destroy(mcf_engine *e);
+
+/* Copies the five arrays the reference pins per call (NS.cs:1701-1705): Source, Target (int32[arc_capacity]),
+ * _cost (int64[arc_capacity]), State (int8[arc_capacity]), _pi (int64[node_count]). */
+MCF_API int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *target,
+                              const int64_t *cost, const int8_t *state, const int64_t *pi);
+
+/* State changes of ChangeFlow (NS.cs:1030-1039): at most two per pivot.  Queued; ordered before the next search. */
+MCF_API int mcf_engine_patch_state(mcf_engine *e, int32_t count, const int32_t *arcs, const int8_t *states);
+
+/* UpdatePotentials (NS.cs:1185-1209): pi[nodes[i]] += sigma.  The caller walks the thread list (it owns the tree);
+ * nodes must be distinct.  Queued; ordered before the next search. */
+MCF_API int mcf_engine_update_potential(mcf_engine *e, int32_t count, const int32_t *nodes, int64_t sigma);
+
+/* Rewrites (source, target, cost) of arcs, e.g. artificial arcs re-pointed by a warm start. Synchronous. */
+MCF_API int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, const int32_t *source,
+                                  const int32_t *target, const int64_t *cost);
+
+/* IFindEnteringArc.FindEnteringArc (NS.cs:1286-1289, :1699-1723): blocking.  *found = 0/1; *arc = entering arc;
+ * *reduced_cost = state*(cost + pi[source] - pi[target]) of that arc.  Advances the rule's internal next_arc exactly
+ * as the selected reference implementation does. */
+MCF_API int mcf_engine_find_entering(mcf_engine *e, int32_t *found, int32_t *arc, int64_t *reduced_cost);
+
+/* Sharded search: the local candidate of this engine's shard, as an exchangeable 16-byte record. */
+typedef struct mcf_candidate {
+    int64_t reduced_cost;   /* 0 when none */
+    uint32_t pos;           /* scan position (rule dependent ordering key); 0xFFFFFFFF when none */
+    int32_t arc;            /* -1 when none */
+} mcf_candidate;
+MCF_API int mcf_engine_find_entering_local(mcf_engine *e, mcf_candidate *out);
+/* Picks the global winner among `count` candidates (one per shard) with the rule's exact tie-breaking and advances
+ * next_arc on THIS engine (every rank calls it with the same gathered array).  *found / *arc as above. */
+MCF_API int mcf_engine_resolve(mcf_engine *e, int32_t count, const mcf_candidate *all, int32_t *found,
+                               int32_t *arc, int64_t *reduced_cost);
+/* contiguous shard of [0, search_arc_num) for rank r of R, aligned to 4 arcs */
+MCF_API int mcf_shard_range(int32_t search_arc_num, int32_t rank, int32_t world, int32_t *begin, int32_t *end);
+
+MCF_API int mcf_engine_get_next_arc(mcf_engine *e, int32_t *next_arc);
+MCF_API int mcf_engine_set_next_arc(mcf_engine *e, int32_t next_arc);
+MCF_API int mcf_engine_get_block_size(mcf_engine *e, int32_t *block_size);
+
+/* parity checks */
+MCF_API int mcf_engine_download_pi(mcf_engine *e, int64_t *pi_out /* [node_count] */);
+MCF_API int mcf_engine_download_state(mcf_engine *e, int8_t *state_out /* [arc_capacity] */);
+
+typedef struct mcf_engine_stats {
+    int64_t searches;             /* find_entering calls */
+    int64_t scan_launches;        /* scan kernel dispatches */
+    int64_t update_launches;      /* separate update kernel dispatches */
+    int64_t inline_updates;       /* searches that carried their patches inside the scan dispatch */
+    int64_t potential_nodes;      /* sum of update_potential counts */
+    int64_t arcs_scanned;         /* sum over scan dispatches of arcs read */
+    int64_t timed_scans;          /* scan dispatches timed with HIP events */
+    double timed_scan_ns;         /* sum of their device durations, ns */
+    double host_wait_ns;          /* host time spent waiting for device answers */
+    double host_launch_ns;        /* host time spent inside launch calls */
+    int32_t scan_workgroups, scan_threads;
+    int64_t bytes_per_scan;       /* algorithmic bytes of one scan: SURVEY.md 8d */
+} mcf_engine_stats;
+MCF_API int mcf_engine_get_stats(mcf_engine *e, mcf_engine_stats *out);
+MCF_API int mcf_engine_reset_stats(mcf_engine *e);
+
+/* Scan-only micro-benchmark on the engine's resident arrays: `reps` back-to-back scan dispatches, each timed with HIP
+ * events on the engine's stream; cold != 0 streams `flush_bytes` through the caches before every repetition.
+ * Results are not consumed (next_arc untouched).  avg/min in ns. */
+MCF_API int mcf_engine_bench_scan(mcf_engine *e, int32_t reps, int32_t cold, int64_t flush_bytes,
+                                  double *avg_ns, double *min_ns);
+
+/* RCCL exchange for sharded engines: one ncclAllGather of 16 bytes per rank per pivot on the engine's stream.
+ * id_out/id: the 128-byte ncclUniqueId, created on rank 0 and broadcast by the caller (torch.distributed). */
+MCF_API int mcf_comm_unique_id(uint8_t id_out[128]);
+MCF_API int mcf_engine_comm_init(mcf_engine *e, const uint8_t id[128], int32_t rank, int32_t world);
+/* find_entering_local + all-gather + resolve in one call */
+MCF_API int mcf_engine_find_entering_sharded(mcf_engine *e, int32_t *found, int32_t *arc, int64_t *reduced_cost);
+
+/* ------------------------------------------------------------------------------------------------
+ * (2) Host driver: NetworkSimplex restated (mirror of the public surface of NS.cs)
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct mcf_ns mcf_ns;
+
+/* NetworkSimplex(IGraph graph) (NS.cs:119-148): the graph is given as flat arc lists, ids = positions */
+MCF_API int mcf_ns_create(mcf_ns **out, int32_t node_count, int32_t arc_count, const int32_t *source, const int32_t *target);
+MCF_API void mcf_ns_destroy(mcf_ns *s);
+MCF_API int mcf_ns_set_arc_bounds(mcf_ns *s, int32_t arc, int64_t lower, int64_t upper);   /* NS.cs:153-164 */
+MCF_API int mcf_ns_set_arc_cost(mcf_ns *s, int32_t arc, int64_t cost);                     /* NS.cs:169-178 */
+MCF_API int mcf_ns_set_node_supply(mcf_ns *s, int32_t node, int64_t supply);               /* NS.cs:183-192 */
+/* bulk forms of the three setters (NULL = keep defaults: lower 0, upper INF, cost 0, supply 0: NS.cs:614-621) */
+MCF_API int mcf_ns_set_problem(mcf_ns *s, const int64_t *lower, const int64_t *upper, const int64_t *cost, const int64_t *supply);
+MCF_API int mcf_ns_set_supply_type(mcf_ns *s, int32_t type);                               /* NS.cs:197-201 */
+MCF_API int mcf_ns_set_pivot_rule(mcf_ns *s, int32_t rule);                                /* NS.cs:206-210 */
+MCF_API int mcf_ns_enable_optimized_pivot(mcf_ns *s, int32_t enable);                      /* NS.cs:532-535 */
+/* device-side options that have no counterpart in the reference */
+MCF_API int mcf_ns_set_device(mcf_ns *s, int32_t device, int32_t int_width /* 32, 64, 0 = narrowest that is safe */,
+                              int32_t block_size /* 0 = reference default */, int32_t engine_flags);
+/* shard the arc scan over `world` ranks exchanging over RCCL (every rank runs the same host loop) */
+MCF_API int mcf_ns_set_sharding(mcf_ns *s, const uint8_t nccl_id[128], int32_t rank, int32_t world);
+
+/* Optional: everything Solve() does before its pivot loop (CheckBounds, TransformToStandardForm, Initialize, creating the
+ * engine and copying the SoA arrays into HBM).  mcf_ns_solve() calls it when the caller has not. */
+MCF_API int mcf_ns_prepare(mcf_ns *s);
+/* Solve() (NS.cs:215-411).  *status receives a mcf_solver_status. */
+MCF_API int mcf_ns_solve(mcf_ns *s, int32_t *status);
+MCF_API int mcf_ns_status(mcf_ns *s, int32_t *status);                                     /* NS.cs:470 */
+MCF_API int mcf_ns_get_flow(mcf_ns *s, int32_t arc, int64_t *flow);                        /* NS.cs:416-429 */
+MCF_API int mcf_ns_get_potential(mcf_ns *s, int32_t node, int64_t *potential);             /* NS.cs:434-447 */
+MCF_API int mcf_ns_get_total_cost(mcf_ns *s, int64_t *cost);                               /* NS.cs:452-465 */
+MCF_API int mcf_ns_get_flows(mcf_ns *s, int64_t *flow_out /* [arc_count] */);
+MCF_API int mcf_ns_get_potentials(mcf_ns *s, int64_t *pi_out /* [node_count] */);
+MCF_API int mcf_ns_get_arc_upper_bound(mcf_ns *s, int32_t arc, int64_t *upper);            /* NS.cs:519-527 (reduced after Solve, D11) */
+
+/* SolverMetrics (OptimizationTypes.cs:43-70), same three phase buckets */
+typedef struct mcf_ns_metrics {
+    int64_t iterations;
+    double total_solve_us, pivot_search_us, tree_update_us, potential_update_us;
+    double setup_us;              /* mcf_ns_prepare: standard form, start basis, engine creation, upload */
+    double loop_us;               /* the pivot loop alone (inputs already resident in HBM) */
+    int32_t search_arc_num, block_size, int_width, reserved;
+    int64_t degenerate_pivots, potential_nodes;
+    mcf_engine_stats engine;
+} mcf_ns_metrics;
+MCF_API int mcf_ns_get_metrics(mcf_ns *s, mcf_ns_metrics *out);                            /* NS.cs:584-587 */
+/* optional pivot trace: entering arc of every pivot of the next Solve() (for parity tests) */
+MCF_API int mcf_ns_set_trace(mcf_ns *s, int32_t *trace, int64_t capacity);
+MCF_API int mcf_ns_get_trace_length(mcf_ns *s, int64_t *length);
+
+/* Stepwise host side, the part a C# host keeps (NS.cs:253, :319-340, :360-388).  None of these searches for an
+ * entering arc; they let the sequential part be driven (and tested) with entering arcs supplied by the caller. */
+MCF_API int mcf_ns_begin(mcf_ns *s, int32_t *status);            /* CheckBounds + TransformToStandardForm + Initialize */
+MCF_API int mcf_ns_apply_pivot(mcf_ns *s, int32_t entering_arc, int32_t *unbounded);   /* FindJoinNode .. UpdatePotentials */
+MCF_API int mcf_ns_finish(mcf_ns *s, int32_t *status);           /* CheckFeasibility + lower-bound restore */
+/* views of the internal SoA after mcf_ns_begin (valid until destroy); sizes: arc_capacity / node_count + 1 */
+MCF_API int mcf_ns_internal(mcf_ns *s, int32_t *search_arc_num, int32_t *arc_capacity, const int32_t **source,
+                            const int32_t **target, const int64_t **cost, const int8_t **state, const int64_t **pi);
+/* what the last mcf_ns_apply_pivot changed: the engine calls a host would make */
+MCF_API int mcf_ns_last_pivot(mcf_ns *s, int32_t *n_state, int32_t arcs[2], int8_t states[2], int32_t *n_nodes,
+                              const int32_t **nodes, int64_t *sigma);
+
+/* ------------------------------------------------------------------------------------------------
+ * Problem sources (build-owned; the reference ships NETGEN outputs but no generator: SURVEY.md F6, 8d)
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct mcf_problem {
+    int32_t node_count, arc_count;
+    int32_t *source, *target;          /* [arc_count], 0-based */
+    int64_t *lower, *upper, *cost;     /* [arc_count] */
+    int64_t *supply;                   /* [node_count] */
+} mcf_problem;
+MCF_API void mcf_problem_free(mcf_problem *p);
+/* NETGEN-like transshipment network: SplitMix64(seed); n_src sources / n_snk sinks, total supply 1000*n_src,
+ * skeleton chains source -> ... -> sink (cost = max_cost, capacity >= the chain's supply) make it feasible;
+ * remaining arcs uniform; arcs are emitted grouped by tail node like NETGEN's output files. */
+MCF_API int mcf_gen_netgen_like(mcf_problem *out, uint64_t seed, int32_t nodes, int32_t arcs, int32_t n_src,
+                                int32_t n_snk, int64_t min_cost, int64_t max_cost, int64_t min_cap, int64_t max_cap);
+/* complete bipartite assignment n x n, cost U[min_cost,max_cost], supply +1/-1, bounds [0,1]
+ * (shape of src/MinCostFlow.Problems/Generators/ProblemGenerator.cs:194-232) */
+MCF_API int mcf_gen_assignment(mcf_problem *out, uint64_t seed, int32_t n, int64_t min_cost, int64_t max_cost);
+/* DIMACS min-cost-flow reader / writer (Loaders/DimacsReader.cs:36-147; lemon/dimacs.h:129-186) */
+MCF_API int mcf_dimacs_read(mcf_problem *out, const char *path);
+MCF_API int mcf_dimacs_write(const mcf_problem *p, const char *path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCF_HIP_H */

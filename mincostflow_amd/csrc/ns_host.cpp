@@ -1,0 +1,642 @@
+// ns_host.cpp -- the sequential half of the primal network simplex, kept on the CPU.
+//
+// Restates the host side of the reference solver (NS.cs = src/MinCostFlow.Core/Lemon/Algorithms/
+// NetworkSimplex.cs): problem set-up, transformation to standard form, the artificial-root start
+// basis, and per pivot the cycle search, flow augmentation and spanning-tree surgery on the
+// thread-index representation.  The two data-parallel pieces -- FindEnteringArc and the potential
+// update -- are NOT here: they are calls into the device engine (engine.hip).  There is no CPU
+// entering-arc search in this file or anywhere else in the library.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int8_t kUp = 1, kDown = -1;   // SpanningTree.cs:67-71 DIR_UP / DIR_DOWN
+constexpr int64_t kMax = INT64_MAX;     // NS.cs:126
+constexpr int64_t kInf = INT64_MAX / 2; // NS.cs:127
+
+}  // namespace
+
+struct mcf_ns {
+    int n = 0, m = 0, root = 0;
+    int search_arcs = 0, all_arcs = 0;
+    int supply_type = MCF_SUPPLY_GEQ, rule = MCF_RULE_BLOCK_SEARCH;   // NS.cs:38, :77
+    bool optimized_pivot = false;                                      // NS.cs:34
+    int device = 0, int_width = 0, block_size = 0, engine_flags = 0;
+    // arcs: m + 2n entries (NS.cs:130)
+    std::vector<int32_t> tail, head;
+    std::vector<int64_t> lower, upper, cost, flow, orig_lower;
+    std::vector<int8_t> state;
+    // nodes: n + 1 entries, the last one is the artificial root (NS.cs:137,144)
+    std::vector<int64_t> supply, pi;
+    std::vector<int32_t> par, par_arc, nxt, prv, sub, fin;   // Parent, Pred, Thread, RevThread, SuccNum, LastSucc
+    std::vector<int8_t> par_dir;
+    std::vector<int32_t> scratch;
+    int64_t sum_supply = 0, art_cost = 0;
+    int status = MCF_NOT_SOLVED;
+    bool begun = false, transformed = false, prepared = false, solved = false;
+    // the pivot being carried out
+    int in_arc = -1, join = -1, u_in = -1, v_in = -1, u_out = -1, v_out = -1;
+    int64_t delta = 0;
+    // what the last pivot changed (the engine calls of a host)
+    int n_state = 0;
+    int32_t st_arc[2] = {0, 0};
+    int8_t st_val[2] = {0, 0};
+    std::vector<int32_t> moved;
+    int64_t sigma = 0;
+    // engine + sharding
+    mcf_engine *engine = nullptr;
+    bool sharded = false;
+    uint8_t nccl_id[128];
+    int rank = 0, world = 1;
+    // trace / metrics
+    int32_t *trace = nullptr;
+    int64_t trace_cap = 0, trace_len = 0;
+    mcf_ns_metrics metrics{};
+};
+
+namespace {
+
+// ---- NS.cs:624-669
+bool bounds_ok(const mcf_ns *s)
+{
+    for (int e = 0; e < s->m; ++e)
+        if (s->upper[e] < s->lower[e]) return false;
+    return true;
+}
+
+void to_standard_form(mcf_ns *s)
+{
+    for (int e = 0; e < s->m; ++e) {
+        const int64_t lo = s->lower[e];
+        if (lo == 0) continue;
+        s->supply[s->tail[e]] -= lo;
+        s->supply[s->head[e]] += lo;
+        s->upper[e] -= lo;
+        s->lower[e] = 0;
+    }
+    s->sum_supply = 0;
+    for (int v = 0; v < s->n; ++v) s->sum_supply += s->supply[v];
+    int64_t biggest = 0;
+    for (int e = 0; e < s->m; ++e) biggest = std::max<int64_t>(biggest, s->cost[e] < 0 ? -s->cost[e] : s->cost[e]);
+    s->art_cost = (biggest + 1) * (int64_t)s->n;
+    s->transformed = true;
+}
+
+// ---- NS.cs:671-845: star basis on the artificial root.  GEQ: nodes with supply <= 0 hang on a zero-cost
+// root->v arc, the others on an ART_COST v->root arc and get a zero-cost root->v arc at its lower bound; LEQ mirrored.
+void start_basis(mcf_ns *s)
+{
+    const int n = s->n, m = s->m, root = s->root = n;
+    s->par[root] = -1; s->par_arc[root] = -1; s->nxt[root] = 0; s->prv[0] = root;
+    s->sub[root] = n + 1; s->fin[root] = n - 1; s->par_dir[root] = 0; s->pi[root] = 0;
+    for (int e = 0; e < m; ++e) { s->state[e] = MCF_STATE_LOWER; s->flow[e] = 0; }
+    s->search_arcs = m + n;
+    int extra = m + n;
+    for (int v = 0; v < n; ++v) { s->nxt[v] = v + 1 < n ? v + 1 : root; }
+    for (int v = 0; v < n; ++v) s->prv[s->nxt[v]] = v;
+    const bool geq = s->supply_type == MCF_SUPPLY_GEQ;
+    for (int v = 0; v < n; ++v) {
+        const int link = m + v;
+        s->par[v] = root; s->sub[v] = 1; s->fin[v] = v;
+        const bool plain = geq ? s->supply[v] <= 0 : s->supply[v] >= 0;
+        // direction of the zero-cost link: GEQ root->v, LEQ v->root
+        const int lt = geq ? root : v, lh = geq ? v : root;
+        s->tail[link] = lt; s->head[link] = lh; s->upper[link] = kInf; s->cost[link] = 0;
+        if (plain) {
+            s->par_dir[v] = geq ? kDown : kUp;
+            s->pi[v] = 0;
+            s->par_arc[v] = link;
+            s->flow[link] = geq ? -s->supply[v] : s->supply[v];
+            s->state[link] = MCF_STATE_TREE;
+        } else {
+            s->par_dir[v] = geq ? kUp : kDown;
+            s->pi[v] = geq ? -s->art_cost : s->art_cost;
+            s->par_arc[v] = extra;
+            s->tail[extra] = lh; s->head[extra] = lt;   // the opposite direction
+            s->upper[extra] = kInf;
+            s->flow[extra] = geq ? s->supply[v] : -s->supply[v];
+            s->cost[extra] = s->art_cost;
+            s->state[extra] = MCF_STATE_TREE;
+            s->flow[link] = 0;
+            s->state[link] = MCF_STATE_LOWER;
+            ++extra;
+        }
+    }
+    if (n > 0) s->prv[root] = n - 1;
+    s->all_arcs = extra;
+}
+
+// ---- NS.cs:925-941
+void find_join(mcf_ns *s)
+{
+    int a = s->tail[s->in_arc], b = s->head[s->in_arc];
+    while (a != b) {
+        if (s->sub[a] < s->sub[b]) a = s->par[a];
+        else b = s->par[b];
+    }
+    s->join = a;
+}
+
+// ---- NS.cs:943-1010.  Ties: strict '<' on the first path, '<=' on the second, so the last blocking arc in
+// cycle direction leaves (keeps the basis strongly feasible).
+bool find_leaving(mcf_ns *s)
+{
+    int first, second;
+    if (s->state[s->in_arc] == MCF_STATE_LOWER) { first = s->tail[s->in_arc]; second = s->head[s->in_arc]; }
+    else { first = s->head[s->in_arc]; second = s->tail[s->in_arc]; }
+    s->delta = s->upper[s->in_arc];
+    int side = 0;
+    for (int u = first; u != s->join; u = s->par[u]) {
+        const int e = s->par_arc[u];
+        int64_t room = s->flow[e];
+        if (s->par_dir[u] == kDown) room = s->upper[e] >= kMax ? kInf : s->upper[e] - room;
+        if (room < s->delta) { s->delta = room; s->u_out = u; side = 1; }
+    }
+    for (int u = second; u != s->join; u = s->par[u]) {
+        const int e = s->par_arc[u];
+        int64_t room = s->flow[e];
+        if (s->par_dir[u] == kUp) room = s->upper[e] >= kMax ? kInf : s->upper[e] - room;
+        if (room <= s->delta) { s->delta = room; s->u_out = u; side = 2; }
+    }
+    if (side == 1) { s->u_in = first; s->v_in = second; }
+    else { s->u_in = second; s->v_in = first; }
+    return side != 0;
+}
+
+// ---- NS.cs:1012-1040; records the State[] writes the device must see
+void push_flow(mcf_ns *s, bool change)
+{
+    if (s->delta > 0) {
+        const int64_t val = s->state[s->in_arc] * s->delta;
+        s->flow[s->in_arc] += val;
+        for (int u = s->tail[s->in_arc]; u != s->join; u = s->par[u]) s->flow[s->par_arc[u]] -= s->par_dir[u] * val;
+        for (int u = s->head[s->in_arc]; u != s->join; u = s->par[u]) s->flow[s->par_arc[u]] += s->par_dir[u] * val;
+    }
+    s->n_state = 0;
+    auto set_state = [&](int arc, int8_t v) {
+        s->state[arc] = v;
+        s->st_arc[s->n_state] = arc;
+        s->st_val[s->n_state] = v;
+        s->n_state++;
+    };
+    if (change) {
+        set_state(s->in_arc, MCF_STATE_TREE);
+        const int out = s->par_arc[s->u_out];
+        set_state(out, s->flow[out] == 0 ? MCF_STATE_LOWER : MCF_STATE_UPPER);
+    } else {
+        set_state(s->in_arc, (int8_t)-s->state[s->in_arc]);
+    }
+}
+
+// ---- NS.cs:1042-1183.  The subtree of u_out is cut off v_out, re-rooted at u_in and hung below v_in; the preorder
+// (thread) list is spliced accordingly and SuccNum / LastSucc are repaired along the two root paths.
+void rehang_subtree(mcf_ns *s)
+{
+    auto &par = s->par; auto &parc = s->par_arc; auto &nxt = s->nxt; auto &prv = s->prv;
+    auto &sub = s->sub; auto &fin = s->fin; auto &pdir = s->par_dir;
+    const int u_in = s->u_in, v_in = s->v_in, u_out = s->u_out, in_arc = s->in_arc, join = s->join;
+    const int before_out = prv[u_out], size_out = sub[u_out], fin_out_old = fin[u_out];
+    const int v_out = s->v_out = par[u_out];
+    const int8_t dir_in = u_in == s->tail[in_arc] ? kUp : kDown;
+
+    if (u_in == u_out) {
+        // the whole subtree moves as it is
+        par[u_in] = v_in; parc[u_in] = in_arc; pdir[u_in] = dir_in;
+        if (nxt[v_in] != u_out) {
+            int after = nxt[fin_out_old];
+            nxt[before_out] = after; prv[after] = before_out;          // unlink [u_out .. fin_out_old]
+            after = nxt[v_in];
+            nxt[v_in] = u_out; prv[u_out] = v_in;                       // relink right behind v_in
+            nxt[fin_out_old] = after; prv[after] = fin_out_old;
+        }
+    } else {
+        // before_out == v_in also means join == v_out
+        const int resume = before_out == v_in ? nxt[fin_out_old] : nxt[v_in];
+        int stem = u_in, new_par = v_in, last = fin[u_in], after = nxt[last];
+        nxt[v_in] = u_in;
+        int n_dirty = 0;
+        s->scratch[n_dirty++] = v_in;
+        while (stem != u_out) {
+            const int up = par[stem];
+            nxt[last] = up;                       // the next stem node follows this stem's subtree
+            s->scratch[n_dirty++] = last;
+            const int before = prv[stem];         // drop the stem's subtree from its old place
+            nxt[before] = after; prv[after] = before;
+            par[stem] = new_par;
+            new_par = stem;
+            stem = up;
+            last = fin[stem] == fin[new_par] ? prv[new_par] : fin[stem];
+            after = nxt[last];
+        }
+        par[u_out] = new_par;
+        nxt[last] = resume; prv[resume] = last;
+        fin[u_out] = last;
+        if (before_out != v_in) { nxt[before_out] = after; prv[after] = before_out; }
+        for (int i = 0; i < n_dirty; ++i) { const int u = s->scratch[i]; prv[nxt[u]] = u; }
+        // reverse the parent arcs along the stem, rebuild sizes
+        int acc = 0;
+        const int fin_new = fin[u_out];
+        for (int u = u_out, p = par[u]; u != u_in; u = p, p = par[u]) {
+            parc[u] = parc[p];
+            pdir[u] = (int8_t)-pdir[p];
+            acc += sub[u] - sub[p];
+            sub[u] = acc;
+            fin[p] = fin_new;
+        }
+        parc[u_in] = in_arc; pdir[u_in] = dir_in; sub[u_in] = size_out;
+    }
+
+    const int stop_out = fin[join] == v_in ? join : -1;
+    const int fin_moved = fin[u_out];
+    for (int u = v_in; u != -1 && fin[u] == v_in; u = par[u]) fin[u] = fin_moved;
+    if (join != before_out && v_in != before_out) {
+        for (int u = v_out; u != stop_out && fin[u] == fin_out_old; u = par[u]) fin[u] = before_out;
+    } else if (fin_moved != fin_out_old) {
+        for (int u = v_out; u != stop_out && fin[u] == fin_out_old; u = par[u]) fin[u] = fin_moved;
+    }
+    for (int u = v_in; u != join; u = par[u]) sub[u] += size_out;
+    for (int u = v_out; u != join; u = par[u]) sub[u] -= size_out;
+}
+
+// ---- NS.cs:1185-1209: host copy of pi is kept current (sigma needs pi[v_in], pi[u_in]); the node list is what
+// mcf_engine_update_potential ships to the device.
+void shift_potentials(mcf_ns *s)
+{
+    s->sigma = s->pi[s->v_in] - s->pi[s->u_in] - s->par_dir[s->u_in] * s->cost[s->in_arc];
+    const int stop = s->nxt[s->fin[s->u_in]];
+    for (int u = s->u_in; u != stop; u = s->nxt[u]) {
+        s->pi[u] += s->sigma;
+        s->moved.push_back(u);
+    }
+}
+
+// one pivot with a given entering arc; returns true when the problem is found unbounded (NS.cs:321-325)
+bool pivot(mcf_ns *s, int arc, double *t_tree, double *t_pot)
+{
+    s->in_arc = arc;
+    s->moved.clear();
+    s->sigma = 0;
+    find_join(s);
+    const bool change = find_leaving(s);
+    if (!change && s->delta == 0) return true;
+    push_flow(s, change);
+    if (s->delta == 0) s->metrics.degenerate_pivots++;
+    if (change) {
+        const double t0 = mcf::now_ns();
+        rehang_subtree(s);
+        const double t1 = mcf::now_ns();
+        shift_potentials(s);
+        const double t2 = mcf::now_ns();
+        if (t_tree) *t_tree += t1 - t0;
+        if (t_pot) *t_pot += t2 - t1;
+    }
+    return false;
+}
+
+int begin(mcf_ns *s, int32_t *status)
+{
+    s->status = MCF_NOT_SOLVED;
+    s->metrics = mcf_ns_metrics{};
+    s->trace_len = 0;
+    if (s->begun) return mcf::fail(MCF_ERR_STATE, "Solve() is single-shot: the reference mutates bounds and supplies in place (NS.cs:649, D11); create a new solver");
+    s->begun = true;
+    if (!bounds_ok(s)) { s->status = MCF_INFEASIBLE; if (status) *status = s->status; return MCF_OK; }   // NS.cs:227-231
+    to_standard_form(s);
+    start_basis(s);
+    if (status) *status = s->status;
+    return MCF_OK;
+}
+
+void finish(mcf_ns *s)
+{
+    // NS.cs:1272-1283 with _allArcNum overwritten by _searchArcNum at NS.cs:689 (difference D9): only the n root links
+    for (int e = s->m; e < s->search_arcs; ++e)
+        if (s->flow[e] != 0) { s->status = MCF_INFEASIBLE; return; }
+    s->status = MCF_OPTIMAL;
+    for (int e = 0; e < s->m; ++e) {                      // NS.cs:364-388
+        const int64_t lo = s->orig_lower[e];
+        if (lo == 0) continue;
+        s->flow[e] += lo;
+        s->supply[s->tail[e]] += lo;
+        s->supply[s->head[e]] -= lo;
+    }
+}
+
+int pick_int_width(const mcf_ns *s)
+{
+    if (s->int_width == 32 || s->int_width == 64) return s->int_width;
+    // |pi| <= ART_COST + n * max|cost| <= 2 * ART_COST; the device forms cost + pi - pi in 64 bits, so each
+    // operand just has to fit int32.  ART_COST = (max|cost| + 1) * n (NS.cs:668).
+    const __int128 bound = (__int128)4 * s->art_cost;
+    return bound < (__int128)INT32_MAX ? 32 : 64;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcf_ns_create(mcf_ns **out, int32_t node_count, int32_t arc_count, const int32_t *source, const int32_t *target)
+{
+    if (!out) return mcf::fail(MCF_ERR_INVALID, "mcf_ns_create: null argument");
+    *out = nullptr;
+    if (node_count < 0 || arc_count < 0 || (arc_count && (!source || !target))) return mcf::fail(MCF_ERR_INVALID, "graph must not be null (NS.cs:121)");
+    if ((int64_t)arc_count + 2 * (int64_t)node_count > INT32_MAX - 4096) return mcf::fail(MCF_ERR_INVALID, "graph too large for 32-bit arc ids");
+    for (int e = 0; e < arc_count; ++e)
+        if ((unsigned)source[e] >= (unsigned)node_count || (unsigned)target[e] >= (unsigned)node_count)
+            return mcf::fail(MCF_ERR_INVALID, "arc %d: end point out of range", e);
+    mcf_ns *s = new mcf_ns();
+    s->n = node_count; s->m = arc_count;
+    const size_t A = (size_t)arc_count + 2 * (size_t)node_count, N = (size_t)node_count + 1;
+    s->tail.assign(A, 0); s->head.assign(A, 0);
+    std::copy(source, source + arc_count, s->tail.begin());
+    std::copy(target, target + arc_count, s->head.begin());
+    s->lower.assign(A, 0); s->upper.assign(A, kInf); s->cost.assign(A, 0); s->flow.assign(A, 0);   // NS.cs:614-617
+    s->orig_lower.assign(arc_count, 0);
+    s->state.assign(A, 0);
+    s->supply.assign(N, 0); s->pi.assign(N, 0);
+    s->par.assign(N, -1); s->par_arc.assign(N, -1); s->nxt.assign(N, 0); s->prv.assign(N, 0);
+    s->sub.assign(N, 0); s->fin.assign(N, 0); s->par_dir.assign(N, 0); s->scratch.assign(N + 1, 0);
+    *out = s;
+    return MCF_OK;
+}
+
+void mcf_ns_destroy(mcf_ns *s)
+{
+    if (!s) return;
+    if (s->engine) mcf_engine_destroy(s->engine);
+    delete s;
+}
+
+int mcf_ns_set_arc_bounds(mcf_ns *s, int32_t arc, int64_t lower, int64_t upper)
+{
+    if (!s || arc < 0 || arc >= s->m) return mcf::fail(MCF_ERR_INVALID, "Invalid arc");
+    s->lower[arc] = lower;
+    s->upper[arc] = upper == MCF_INF_CAP ? kInf : upper;
+    s->orig_lower[arc] = lower;
+    return MCF_OK;
+}
+int mcf_ns_set_arc_cost(mcf_ns *s, int32_t arc, int64_t cost)
+{
+    if (!s || arc < 0 || arc >= s->m) return mcf::fail(MCF_ERR_INVALID, "Invalid arc");
+    s->cost[arc] = cost;
+    return MCF_OK;
+}
+int mcf_ns_set_node_supply(mcf_ns *s, int32_t node, int64_t supply)
+{
+    if (!s || node < 0 || node >= s->n) return mcf::fail(MCF_ERR_INVALID, "Invalid node");
+    s->supply[node] = supply;
+    return MCF_OK;
+}
+int mcf_ns_set_problem(mcf_ns *s, const int64_t *lower, const int64_t *upper, const int64_t *cost, const int64_t *supply)
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    for (int e = 0; e < s->m; ++e) {
+        if (lower) { s->lower[e] = lower[e]; s->orig_lower[e] = lower[e]; }
+        if (upper) s->upper[e] = upper[e] == MCF_INF_CAP ? kInf : upper[e];
+        if (cost) s->cost[e] = cost[e];
+    }
+    if (supply) std::copy(supply, supply + s->n, s->supply.begin());
+    return MCF_OK;
+}
+int mcf_ns_set_supply_type(mcf_ns *s, int32_t type)
+{
+    if (!s || (type != MCF_SUPPLY_GEQ && type != MCF_SUPPLY_LEQ)) return mcf::fail(MCF_ERR_INVALID, "bad supply type");
+    s->supply_type = type;
+    return MCF_OK;
+}
+int mcf_ns_set_pivot_rule(mcf_ns *s, int32_t rule)
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    if (rule < 0 || rule > 2) return mcf::fail(MCF_ERR_INVALID, "Pivot rule %d not implemented yet (NS.cs:884)", rule);
+    s->rule = rule;
+    return MCF_OK;
+}
+int mcf_ns_enable_optimized_pivot(mcf_ns *s, int32_t enable)
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    s->optimized_pivot = enable != 0;
+    return MCF_OK;
+}
+int mcf_ns_set_device(mcf_ns *s, int32_t device, int32_t int_width, int32_t block_size, int32_t engine_flags)
+{
+    if (!s || (int_width != 0 && int_width != 32 && int_width != 64) || block_size < 0 || device < 0) return mcf::fail(MCF_ERR_INVALID, "mcf_ns_set_device: bad arguments");
+    s->device = device; s->int_width = int_width; s->block_size = block_size; s->engine_flags = engine_flags;
+    return MCF_OK;
+}
+int mcf_ns_set_sharding(mcf_ns *s, const uint8_t id[128], int32_t rank, int32_t world)
+{
+    if (!s || !id || world < 1 || rank < 0 || rank >= world) return mcf::fail(MCF_ERR_INVALID, "mcf_ns_set_sharding: bad arguments");
+    memcpy(s->nccl_id, id, 128);
+    s->rank = rank; s->world = world; s->sharded = world > 1;
+    return MCF_OK;
+}
+int mcf_ns_set_trace(mcf_ns *s, int32_t *trace, int64_t capacity)
+{
+    if (!s || capacity < 0) return mcf::fail(MCF_ERR_INVALID, "bad trace buffer");
+    s->trace = trace; s->trace_cap = trace ? capacity : 0; s->trace_len = 0;
+    return MCF_OK;
+}
+int mcf_ns_get_trace_length(mcf_ns *s, int64_t *length) { if (!s || !length) return mcf::fail(MCF_ERR_INVALID, "null argument"); *length = s->trace_len; return MCF_OK; }
+
+int mcf_ns_begin(mcf_ns *s, int32_t *status)
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    return begin(s, status);
+}
+
+int mcf_ns_apply_pivot(mcf_ns *s, int32_t arc, int32_t *unbounded)
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    if (!s->transformed) return mcf::fail(MCF_ERR_STATE, "mcf_ns_begin has not been called (or found the bounds infeasible)");
+    if (arc < 0 || arc >= s->search_arcs) return mcf::fail(MCF_ERR_INVALID, "entering arc %d outside the search range [0, %d)", arc, s->search_arcs);
+    if (s->state[arc] == MCF_STATE_TREE) return mcf::fail(MCF_ERR_INVALID, "arc %d is in the basis and cannot enter", arc);
+    const bool unb = pivot(s, arc, nullptr, nullptr);
+    if (unb) s->status = MCF_UNBOUNDED; else s->metrics.iterations++;
+    if (unbounded) *unbounded = unb ? 1 : 0;
+    return MCF_OK;
+}
+
+int mcf_ns_finish(mcf_ns *s, int32_t *status)
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    if (!s->transformed) return mcf::fail(MCF_ERR_STATE, "mcf_ns_begin has not been called");
+    if (s->status != MCF_UNBOUNDED) finish(s);
+    if (status) *status = s->status;
+    return MCF_OK;
+}
+
+int mcf_ns_internal(mcf_ns *s, int32_t *search_arc_num, int32_t *arc_capacity, const int32_t **source, const int32_t **target,
+                    const int64_t **cost, const int8_t **state, const int64_t **pi)
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    if (search_arc_num) *search_arc_num = s->search_arcs;
+    if (arc_capacity) *arc_capacity = (int32_t)s->tail.size();
+    if (source) *source = s->tail.data();
+    if (target) *target = s->head.data();
+    if (cost) *cost = s->cost.data();
+    if (state) *state = s->state.data();
+    if (pi) *pi = s->pi.data();
+    return MCF_OK;
+}
+
+int mcf_ns_last_pivot(mcf_ns *s, int32_t *n_state, int32_t arcs[2], int8_t states[2], int32_t *n_nodes, const int32_t **nodes, int64_t *sigma)
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    if (n_state) *n_state = s->n_state;
+    for (int i = 0; i < s->n_state; ++i) { if (arcs) arcs[i] = s->st_arc[i]; if (states) states[i] = s->st_val[i]; }
+    if (n_nodes) *n_nodes = (int32_t)s->moved.size();
+    if (nodes) *nodes = s->moved.data();
+    if (sigma) *sigma = s->sigma;
+    return MCF_OK;
+}
+
+// ---- everything of Solve() (NS.cs:215-411) that precedes the pivot loop
+int mcf_ns_prepare(mcf_ns *s)
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    if (s->prepared) return MCF_OK;
+    if (mcf_device_count() <= s->device)
+        return mcf::fail(MCF_ERR_NO_DEVICE, "HIP device %d not available (%d visible); the entering-arc search only exists on the device", s->device, mcf_device_count());
+    const double t_start = mcf::now_ns();
+    int rc = begin(s, nullptr);
+    if (rc) return rc;
+    s->prepared = true;
+    if (s->status == MCF_INFEASIBLE) return MCF_OK;
+
+    // CreatePivotRuleFinder (NS.cs:847-886): the finder is the device engine
+    mcf_engine_desc d{};
+    d.node_count = s->n + 1;
+    d.arc_capacity = (int32_t)s->tail.size();
+    d.search_arc_num = s->search_arcs;
+    d.int_width = pick_int_width(s);
+    d.rule = s->rule;
+    d.semantics = s->optimized_pivot ? MCF_SEM_OPTIMIZED : MCF_SEM_PLAIN;
+    d.block_size = s->block_size;
+    d.device = s->device;
+    d.flags = s->engine_flags;
+    if (s->sharded) { rc = mcf_shard_range(s->search_arcs, s->rank, s->world, &d.shard_begin, &d.shard_end); if (rc) return rc; }
+    if (s->engine) { mcf_engine_destroy(s->engine); s->engine = nullptr; }
+    rc = mcf_engine_create(&s->engine, &d);
+    if (rc) return rc;
+    rc = mcf_engine_upload(s->engine, s->tail.data(), s->head.data(), s->cost.data(), s->state.data(), s->pi.data());
+    if (rc) return rc;
+    if (s->sharded) { rc = mcf_engine_comm_init(s->engine, s->nccl_id, s->rank, s->world); if (rc) return rc; }
+    s->metrics.search_arc_num = s->search_arcs;
+    s->metrics.int_width = d.int_width;
+    mcf_engine_get_block_size(s->engine, &s->metrics.block_size);
+    s->metrics.setup_us = (mcf::now_ns() - t_start) / 1e3;
+    return MCF_OK;
+}
+
+// ---- Solve(): NS.cs:215-411
+int mcf_ns_solve(mcf_ns *s, int32_t *status)
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    if (s->solved) return mcf::fail(MCF_ERR_STATE, "Solve() is single-shot (NS.cs:649, D11); create a new solver");
+    int rc = mcf_ns_prepare(s);
+    if (rc) return rc;
+    s->solved = true;
+    if (s->status == MCF_INFEASIBLE) { if (status) *status = s->status; return MCF_OK; }
+    const double t_start = mcf::now_ns();
+
+    const int64_t max_iter = std::max<int64_t>(1000000, (int64_t)s->n * (int64_t)s->m);   // NS.cs:280
+    int64_t it = 0;
+    double t_search = 0, t_tree = 0, t_pot = 0;
+    for (;;) {
+        const double t0 = mcf::now_ns();
+        int32_t found = 0, arc = -1;
+        rc = s->sharded ? mcf_engine_find_entering_sharded(s->engine, &found, &arc, nullptr)
+                        : mcf_engine_find_entering(s->engine, &found, &arc, nullptr);
+        t_search += mcf::now_ns() - t0;
+        if (rc) return rc;
+        if (!found) break;
+        if (s->trace && it < s->trace_cap) s->trace[it] = arc;
+        ++it;
+        if (it > max_iter) { s->status = MCF_INFEASIBLE; break; }                          // NS.cs:311-317
+        if (pivot(s, arc, &t_tree, &t_pot)) { s->status = MCF_UNBOUNDED; break; }
+        const double t1 = mcf::now_ns();
+        rc = mcf_engine_patch_state(s->engine, s->n_state, s->st_arc, s->st_val);
+        if (!rc && !s->moved.empty()) rc = mcf_engine_update_potential(s->engine, (int32_t)s->moved.size(), s->moved.data(), s->sigma);
+        t_pot += mcf::now_ns() - t1;
+        if (rc) return rc;
+        s->metrics.potential_nodes += (int64_t)s->moved.size();
+    }
+    s->trace_len = std::min(it, s->trace_cap);
+    s->metrics.iterations = it;
+    if (s->status == MCF_NOT_SOLVED) finish(s);
+    s->metrics.pivot_search_us = t_search / 1e3;
+    s->metrics.tree_update_us = t_tree / 1e3;
+    s->metrics.potential_update_us = t_pot / 1e3;
+    mcf_engine_get_stats(s->engine, &s->metrics.engine);
+    s->metrics.loop_us = (mcf::now_ns() - t_start) / 1e3;
+    s->metrics.total_solve_us = s->metrics.loop_us + s->metrics.setup_us;
+    if (status) *status = s->status;
+    return MCF_OK;
+}
+
+int mcf_ns_status(mcf_ns *s, int32_t *status) { if (!s || !status) return mcf::fail(MCF_ERR_INVALID, "null argument"); *status = s->status; return MCF_OK; }
+
+static int need_optimal(const mcf_ns *s)
+{
+    if (s->status != MCF_OPTIMAL) return mcf::fail(MCF_ERR_STATE, "Solution not optimal");   // NS.cs:418-421
+    return MCF_OK;
+}
+int mcf_ns_get_flow(mcf_ns *s, int32_t arc, int64_t *flow)
+{
+    if (!s || !flow) return mcf::fail(MCF_ERR_INVALID, "null argument");
+    if (int rc = need_optimal(s)) return rc;
+    if (arc < 0 || arc >= s->m) return mcf::fail(MCF_ERR_INVALID, "Invalid arc");
+    *flow = s->flow[arc];
+    return MCF_OK;
+}
+int mcf_ns_get_potential(mcf_ns *s, int32_t node, int64_t *potential)
+{
+    if (!s || !potential) return mcf::fail(MCF_ERR_INVALID, "null argument");
+    if (int rc = need_optimal(s)) return rc;
+    if (node < 0 || node >= s->n) return mcf::fail(MCF_ERR_INVALID, "Invalid node");
+    *potential = s->pi[node];
+    return MCF_OK;
+}
+int mcf_ns_get_total_cost(mcf_ns *s, int64_t *cost)
+{
+    if (!s || !cost) return mcf::fail(MCF_ERR_INVALID, "null argument");
+    if (int rc = need_optimal(s)) return rc;
+    int64_t total = 0;
+    for (int e = 0; e < s->m; ++e) total += s->flow[e] * s->cost[e];   // NS.cs:459-464
+    *cost = total;
+    return MCF_OK;
+}
+int mcf_ns_get_flows(mcf_ns *s, int64_t *out)
+{
+    if (!s || !out) return mcf::fail(MCF_ERR_INVALID, "null argument");
+    if (int rc = need_optimal(s)) return rc;
+    std::copy(s->flow.begin(), s->flow.begin() + s->m, out);
+    return MCF_OK;
+}
+int mcf_ns_get_potentials(mcf_ns *s, int64_t *out)
+{
+    if (!s || !out) return mcf::fail(MCF_ERR_INVALID, "null argument");
+    if (int rc = need_optimal(s)) return rc;
+    std::copy(s->pi.begin(), s->pi.begin() + s->n, out);
+    return MCF_OK;
+}
+int mcf_ns_get_arc_upper_bound(mcf_ns *s, int32_t arc, int64_t *upper)
+{
+    if (!s || !upper) return mcf::fail(MCF_ERR_INVALID, "null argument");
+    if (arc < 0 || arc >= s->m) return mcf::fail(MCF_ERR_INVALID, "Invalid arc");
+    *upper = s->upper[arc];
+    return MCF_OK;
+}
+int mcf_ns_get_metrics(mcf_ns *s, mcf_ns_metrics *out)
+{
+    if (!s || !out) return mcf::fail(MCF_ERR_INVALID, "null argument");
+    *out = s->metrics;
+    return MCF_OK;
+}
+
+}  // extern "C"

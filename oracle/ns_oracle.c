@@ -677,6 +677,20 @@ NSO_API int nso_solve(ns_oracle *o, int32_t *trace, int64_t trace_cap, int64_t *
     return nso_finish(o);
 }
 
+/* At most max_pivots iterations of the main loop (after nso_init / nso_initial_pivots): used to time a bounded sample
+ * of a solve.  Returns 1 when the loop ended by itself (no entering arc / unbounded), 0 when the cap was hit. */
+NSO_API int nso_run_pivots(ns_oracle *o, int64_t max_pivots, int64_t *done)
+{
+    int64_t it = 0; int32_t e; int ended = 0;
+    while (it < max_pivots) {
+        if (!nso_find_entering(o, &e)) { ended = 1; break; }
+        it++;
+        if (nso_apply_pivot(o, e) == NSO_UNBOUNDED) { o->status = NSO_UNBOUNDED; ended = 1; break; }
+    }
+    if (done) *done = it;
+    return ended;
+}
+
 /* ------------------------------------------------------------------ results / introspection */
 
 NSO_API int nso_status(const ns_oracle *o) { return o->status; }

@@ -51,6 +51,7 @@ def lib():
     L.nso_apply_pivot.argtypes = [C.c_void_p, C.c_int32]
     L.nso_finish.argtypes = [C.c_void_p]
     L.nso_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.nso_run_pivots.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     for f in ("nso_status", "nso_search_arc_num", "nso_all_arc_num", "nso_block_size", "nso_next_arc",
               "nso_last_subtree"):
         getattr(L, f).argtypes = [C.c_void_p]
@@ -131,6 +132,12 @@ class Oracle:
 
     def finish(self) -> int:
         return self.L.nso_finish(self.h)
+
+    def run_pivots(self, max_pivots: int):
+        """(ended, pivots_done) -- at most max_pivots iterations of the main loop."""
+        n = C.c_int64(0)
+        ended = self.L.nso_run_pivots(self.h, max_pivots, C.byref(n))
+        return bool(ended), n.value
 
     # whole solve; returns (status, trace[int32]) -- trace = entering arcs of the main loop
     def solve(self, trace_cap: int = 0):

@@ -1,0 +1,270 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+Bit-exact: this is integer work.  Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+import kat_data as K
+import mincostflow_amd as M
+from helpers import fixtures, load, problem_from_dict, validate_solution
+from mincostflow_amd import _lib as L
+from oracle import ns_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RULES = {O.RULE_FIRST: M.PivotRule.FirstEligible, O.RULE_BEST: M.PivotRule.BestEligible, O.RULE_BLOCK: M.PivotRule.BlockSearch}
+
+
+def _random_soa(rng, m_s, n, cost_span, pi_span, extra=7):
+    cap = m_s + extra
+    return dict(src=rng.integers(0, n, cap, dtype=np.int32), tgt=rng.integers(0, n, cap, dtype=np.int32),
+                cost=rng.integers(-cost_span, cost_span + 1, cap, dtype=np.int64),
+                state=rng.integers(-1, 2, cap, dtype=np.int8),
+                pi=rng.integers(-pi_span, 1, n, dtype=np.int64))
+
+
+def _oracle_scan(rule, optimized, a, m_s, block, next_arc):
+    if rule == O.RULE_BEST:
+        f, e, c = O.scan_best(m_s, a["state"], a["cost"], a["src"], a["tgt"], a["pi"]); return f, e, c, next_arc
+    if rule == O.RULE_FIRST:
+        return O.scan_first(m_s, a["state"], a["cost"], a["src"], a["tgt"], a["pi"], next_arc)
+    return O.scan_block(m_s, a["state"], a["cost"], a["src"], a["tgt"], a["pi"], block, optimized, next_arc)
+
+
+@pytest.mark.parametrize("width", [64, 32])
+@pytest.mark.parametrize("rule,optimized", [(O.RULE_BEST, True), (O.RULE_BLOCK, True), (O.RULE_BLOCK, False), (O.RULE_FIRST, True)])
+def test_scan_matches_oracle_on_random_arrays(width, rule, optimized):
+    """Ragged sizes, heavy ties (tiny cost range), random patches between searches (inline and staged paths)."""
+    rng = np.random.default_rng(1234 + width + 10 * rule + optimized)
+    for m_s, n, span in [(1, 2, 3), (3, 2, 2), (4, 5, 2), (5, 3, 50), (1023, 40, 3), (1024, 300, 2), (1025, 7, 10 ** 6),
+                         (4097, 5000, 4), (100003, 20000, 10 ** 4), (2 ** 20 + 5, 3000, 10 ** 5)]:
+        pi_span = 10 ** 9 if width == 64 and span > 100 else span * 3
+        a = _random_soa(rng, m_s, n, span, pi_span)
+        block = int(rng.integers(1, max(2, min(m_s, 700))))
+        eng = M.PivotEngine(n, len(a["src"]), m_s, rule=RULES[rule], optimized=optimized, int_width=width, block_size=block)
+        eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+        next_arc = 0
+        for it in range(12):
+            f, e, c, na = _oracle_scan(rule, optimized, a, m_s, block, next_arc)
+            f2, e2, c2 = eng.find_entering()
+            assert f2 == f, (m_s, it)
+            if f:
+                assert (e2, c2) == (e, c), (m_s, it, rule, optimized, e2, e, c2, c, next_arc, block)
+                if rule != O.RULE_BEST:
+                    assert eng.next_arc == na, (m_s, it, eng.next_arc, na, next_arc, block, e)
+                next_arc = na
+            # random patches: 0..2 state writes; a potential list that is empty / small (inline) / large (staged)
+            k_st = int(rng.integers(0, 3))
+            arcs = rng.choice(len(a["src"]), size=min(k_st, len(a["src"])), replace=False).astype(np.int32)
+            vals = rng.integers(-1, 2, len(arcs)).astype(np.int8)
+            a["state"][arcs] = vals
+            eng.patch_state(arcs, vals)
+            k = int(rng.choice([0, 1, 5, 96, 97, min(n, 3000)]))
+            k = min(k, n)
+            nodes = rng.choice(n, size=k, replace=False).astype(np.int32)
+            sigma = int(rng.integers(-span - 1, span + 2))
+            a["pi"][nodes] += sigma
+            eng.update_potential(nodes, sigma)
+            if it == 5 and rule != O.RULE_BEST:
+                next_arc = int(rng.integers(0, m_s + 1))      # includes next_arc == m_s (BlockSearchPivotOptimized.cs:63,102)
+                eng.next_arc = next_arc
+        assert np.array_equal(eng.download_pi(), a["pi"])
+        assert np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
+        st = eng.stats()
+        assert st["searches"] == 12 and st["inline_updates"] > 0 and st["update_launches"] > 0 or n < 97
+
+
+def test_scan_edge_cases():
+    # empty search range, nothing eligible, everything in the basis
+    eng = M.PivotEngine(3, 4, 0, rule=M.PivotRule.BestEligible)
+    eng.upload(np.zeros(4, np.int32), np.zeros(4, np.int32), np.zeros(4, np.int64), np.zeros(4, np.int8), np.zeros(3, np.int64))
+    assert eng.find_entering() == (False, -1, 0)
+    for rule in RULES.values():
+        eng = M.PivotEngine(4, 9, 9, rule=rule)
+        src = np.arange(9, dtype=np.int32) % 4
+        tgt = (src + 1) % 4
+        eng.upload(src, tgt, np.full(9, 5, np.int64), np.ones(9, np.int8), np.zeros(4, np.int64))   # all rc = +5
+        assert eng.find_entering()[0] is False
+        eng.upload(src, tgt, np.full(9, -5, np.int64), np.zeros(9, np.int8), np.zeros(4, np.int64))  # all tree arcs
+        assert eng.find_entering()[0] is False
+        eng.upload(src, tgt, np.full(9, -5, np.int64), -np.ones(9, np.int8), np.zeros(4, np.int64))  # upper, rc = +5
+        assert eng.find_entering()[0] is False
+    # all reduced costs equal: the lowest arc index wins (strict '<', NetworkSimplex.cs:1653)
+    eng = M.PivotEngine(2, 5000, 5000, rule=M.PivotRule.BestEligible)
+    eng.upload(np.zeros(5000, np.int32), np.ones(5000, np.int32), np.full(5000, -7, np.int64), np.ones(5000, np.int8), np.zeros(2, np.int64))
+    assert eng.find_entering() == (True, 0, -7)
+    eng.patch_state([0, 1, 2], [0, 0, -1])
+    assert eng.find_entering() == (True, 3, -7)
+    # int64 values that need all 64 bits
+    big = np.int64(3) << 60
+    eng = M.PivotEngine(2, 2, 2, rule=M.PivotRule.BestEligible)
+    eng.upload([0, 1], [1, 0], [-big, -big - 1], [1, 1], [0, 0])
+    assert eng.find_entering() == (True, 1, int(-big - 1))
+    with pytest.raises(M.McfError) as ei:      # int32 engine refuses what does not fit
+        e32 = M.PivotEngine(2, 2, 2, int_width=32)
+        e32.upload([0, 1], [1, 0], [-big, 1], [1, 1], [0, 0])
+    assert ei.value.code == L.ERR_OVERFLOW
+    with pytest.raises(M.McfError) as ei:
+        eng.upload([0, 7], [1, 0], [1, 1], [1, 1], [0, 0])     # end point outside the node range
+    assert ei.value.code == L.ERR_INVALID
+
+
+def _solve_both(p, sem, rule, int_width=0, flags=0, supply_type=O.GEQ, block_size=0):
+    o = O.Oracle(p, sem, rule, supply_type=supply_type, block_size=block_size)
+    st_o, tr_o = o.solve(trace_cap=4_000_000)
+    ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
+    ns.set_pivot_rule(RULES[rule]).enable_optimized_pivot(sem == O.SEM_CSHARP_OPT).set_supply_type(supply_type)
+    ns.set_device(0, int_width, block_size, flags).record_trace(4_000_000)
+    st = ns.solve()
+    return o, st_o, tr_o, ns, st
+
+
+@pytest.mark.parametrize("name", ["netgen_8_08a", "netgen_8_10a", "transport_40x30", "circulation_100_0_10", "assignment_50x50",
+                                  "SimpleProblemIllustration2NonSparse", "AURV19V6", "grid_5x5", "star_graph"])
+def test_solve_is_pivot_for_pivot_identical(name):
+    """Same entering arc at every pivot, hence same flows and potentials, for both C# flavours of every rule."""
+    p = load(name)
+    for sem, rule in [(O.SEM_CSHARP_OPT, O.RULE_BLOCK), (O.SEM_CSHARP, O.RULE_BLOCK), (O.SEM_CSHARP_OPT, O.RULE_BEST),
+                      (O.SEM_CSHARP, O.RULE_BEST), (O.SEM_CSHARP_OPT, O.RULE_FIRST), (O.SEM_CSHARP, O.RULE_FIRST)]:
+        if name == "AURV19V6" and rule == O.RULE_FIRST:
+            continue        # 117k pivots, nothing new
+        o, st_o, tr_o, ns, st = _solve_both(p, sem, rule)
+        tr = ns.trace()
+        assert st == st_o == O.OPTIMAL
+        assert len(tr) == len(tr_o) == o.n_pivots, (name, sem, rule, len(tr), len(tr_o))
+        assert np.array_equal(tr, tr_o), (name, sem, rule, int(np.argmax(tr != tr_o)))
+        assert ns.get_total_cost() == o.total_cost
+        assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
+        m = ns.get_metrics()
+        assert m["iterations"] == o.n_pivots and m["block_size"] == o.block_size and m["search_arc_num"] == o.search_arc_num
+
+
+@pytest.mark.parametrize("name,path,want", fixtures(), ids=[f[0] for f in fixtures()])
+def test_every_fixture_reaches_the_sol_cost(name, path, want):
+    """The reference's fixture sweep (PerformanceComparisonReport.cs:253-268): GetTotalCost() == .sol 's' line, through
+    EnableOptimizedPivot(true) + Block Search, plus the validator's optimality certificate."""
+    p = load(path)
+    ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply).enable_optimized_pivot(True)
+    assert ns.solve() == M.SolverStatus.Optimal
+    assert ns.get_total_cost() == want
+    validate_solution(p, ns.flows(), ns.potentials())
+    if p.m <= 10000:
+        nb = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
+        nb.set_pivot_rule(M.PivotRule.BestEligible)
+        assert nb.solve() == M.SolverStatus.Optimal and nb.get_total_cost() == want
+
+
+@pytest.mark.parametrize("kat", K.CSHARP_KATS, ids=[k[0] for k in K.CSHARP_KATS])
+def test_csharp_unit_test_answers_on_gpu(kat):
+    name, d, status, cost, flows = kat
+    p = problem_from_dict(d)
+    seen = set()
+    for optimized in (False, True):                 # OptimizationTests.cs:14-69: same status, cost AND flows
+        for rule in RULES.values():                 # OptimizationTests.cs:75-120: every rule validates
+            ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
+            ns.set_pivot_rule(rule).enable_optimized_pivot(optimized)
+            assert ns.solve() == status and ns.status == status
+            if status != M.SolverStatus.Optimal:
+                with pytest.raises(M.McfError):
+                    ns.get_flow(0)
+                continue
+            if cost is not None:
+                assert ns.get_total_cost() == cost
+            if flows is not None:
+                assert ns.flows().tolist() == flows
+            validate_solution(p, ns.flows(), ns.potentials())
+            if rule == M.PivotRule.BlockSearch:
+                seen.add((ns.get_total_cost(), tuple(ns.flows().tolist())))
+    assert len(seen) <= 1
+
+
+def test_int32_and_int64_device_paths_agree_and_overflow_is_caught():
+    g = M.netgen_like(13502460, 3000, 12000, 50, 50)
+    p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
+    traces = []
+    for w in (32, 64, 0):
+        o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, O.RULE_BLOCK, int_width=w)
+        assert st == st_o == O.OPTIMAL and np.array_equal(ns.trace(), tr_o)
+        traces.append(ns.trace())
+        if w == 0:
+            assert ns.get_metrics()["int_width"] == 32      # (max|c|+1)*n*4 < 2^31
+    assert np.array_equal(traces[0], traces[1])
+    pa = load("AURV19V6")                                    # needs int64 ("never int")
+    ns = M.NetworkSimplex(pa.n, pa.src, pa.tgt).set_problem(pa.lower, pa.upper, pa.cost, pa.supply).set_device(0, 32)
+    with pytest.raises(M.McfError) as ei:
+        ns.solve()
+    assert ei.value.code == L.ERR_OVERFLOW
+    ns = M.NetworkSimplex(pa.n, pa.src, pa.tgt).set_problem(pa.lower, pa.upper, pa.cost, pa.supply)
+    assert ns.solve() == 1 and ns.get_metrics()["int_width"] == 64
+
+
+def test_staged_update_path_equals_inline_path():
+    p = load("netgen_8_10a")
+    o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, O.RULE_BEST, flags=M.ENGINE_NO_INLINE_UPDATE)
+    assert st == 1 and np.array_equal(ns.trace(), tr_o)
+    e = ns.get_metrics()["engine"]
+    assert e["inline_updates"] == 0 and e["update_launches"] > 1000
+    o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, O.RULE_BEST, flags=M.ENGINE_SAMPLE_KERNEL_TIME)
+    e = ns.get_metrics()["engine"]
+    assert np.array_equal(ns.trace(), tr_o) and e["inline_updates"] > 1000 and e["timed_scans"] > 10 and e["timed_scan_ns"] > 0
+
+
+@pytest.mark.parametrize("rule,optimized", [(O.RULE_BEST, True), (O.RULE_BLOCK, True), (O.RULE_BLOCK, False), (O.RULE_FIRST, True)])
+def test_sharded_engines_resolve_like_one_engine(rule, optimized):
+    """Arc shards on separate engines + the MINLOC resolve step give the single-engine answer (same device; the RCCL
+    all-gather only moves the 16-byte records)."""
+    rng = np.random.default_rng(99 + rule)
+    m_s, n, world = 50021, 3000, 3
+    a = _random_soa(rng, m_s, n, 5, 12, extra=0)
+    block = 173
+    one = M.PivotEngine(n, m_s, m_s, rule=RULES[rule], optimized=optimized, block_size=block)
+    one.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+    shards = []
+    for r in range(world):
+        e = M.PivotEngine(n, m_s, m_s, rule=RULES[rule], optimized=optimized, block_size=block, shard=M.shard_range(m_s, r, world))
+        e.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+        shards.append(e)
+    for it in range(10):
+        want = one.find_entering()
+        cands = [e.find_entering_local() for e in shards]
+        got = [e.resolve(cands) for e in shards]
+        assert all(g == want for g in got), (it, want, got)
+        assert all(e.next_arc == one.next_arc for e in shards)
+        if want[0]:
+            arcs = np.array([want[1]], np.int32); vals = np.array([0], np.int8)
+            nodes = rng.choice(n, size=40, replace=False).astype(np.int32)
+            for e in [one] + shards:
+                e.patch_state(arcs, vals)
+                e.update_potential(nodes, -3)
+
+
+def test_full_size_configs_certified_optimal():
+    """BASELINE.json configs 2-4 at full size.  The oracle's Best-Eligible would take minutes here, so parity is checked
+    through size-independent properties: the validator's optimality certificate (primal = dual, complementary slackness,
+    conservation) and equality of the optimal cost with the oracle's Block-Search solve of the same instance."""
+    cases = [
+        ("config2", M.netgen_like(13502460, 10_000, 30_000, 100, 100), M.PivotRule.BlockSearch, 32),
+        ("config3", M.netgen_like(13502460, 100_000, 300_000, 316, 316), M.PivotRule.BestEligible, 64),
+        ("config4", M.assignment(42, 1000, 1, 100), M.PivotRule.BestEligible, 64),
+    ]
+    for name, g, rule, width in cases:
+        p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
+        ns = M.NetworkSimplex.from_problem(g).set_pivot_rule(rule).enable_optimized_pivot(True).set_device(0, width)
+        assert ns.solve() == M.SolverStatus.Optimal, name
+        cost = validate_solution(p, ns.flows(), ns.potentials())
+        assert cost == ns.get_total_cost()
+        o = O.Oracle(p, O.SEM_CSHARP_OPT, O.RULE_BLOCK)
+        assert o.solve()[0] == O.OPTIMAL and o.total_cost == cost, name
+        m = ns.get_metrics()
+        assert m["int_width"] == width and m["iterations"] > 0
+
+
+def test_bench_scan_reports_sane_durations():
+    rng = np.random.default_rng(5)
+    m_s, n = 1 << 20, 100_000
+    a = _random_soa(rng, m_s, n, 10 ** 4, 10 ** 9, extra=0)
+    eng = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible)
+    eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+    avg, mn = eng.bench_scan(reps=10)
+    assert 500 < mn <= avg < 5e6
+    f, e, c = eng.find_entering()
+    assert (f, e, c) == O.scan_best(m_s, a["state"], a["cost"], a["src"], a["tgt"], a["pi"])

@@ -1,0 +1,229 @@
+"""CPU tests of the product's host side: the C ABI surface, the sequential pivot driver (replayed against the oracle
+with entering arcs supplied by the test -- the library itself has no CPU search), generators, DIMACS I/O, errors."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import kat_data as K
+import mincostflow_amd as M
+from helpers import fixtures, load, problem_from_dict, validate_solution
+from mincostflow_amd import _lib as L
+from oracle import ns_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mcf_hip.h")).read()
+    declared = set(re.findall(r"MCF_API\s+[\w\s\*]+?\b(mcf_\w+)\s*\(", header))
+    assert len(declared) >= 55
+    lib = C.CDLL(M.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/mcf_hip.h but not exported"
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    assert b"gfx950" in L.lib().mcf_version()
+
+
+def test_no_cpu_search_path_without_device(have_gpu):
+    if have_gpu:
+        pytest.skip("a GPU is present")
+    p = load("transport_2x3")
+    ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
+    with pytest.raises(M.McfError) as ei:
+        ns.solve()
+    assert ei.value.code == L.ERR_NO_DEVICE
+    with pytest.raises(M.McfError) as ei:
+        M.PivotEngine(10, 20, 20)
+    assert ei.value.code == L.ERR_NO_DEVICE
+
+
+def _replay(p, sem, rule, supply_type=O.GEQ):
+    o = O.Oracle(p, sem, rule, supply_type=supply_type)
+    ok = o.init()
+    ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply).set_supply_type(supply_type)
+    st = ns.begin()
+    if not ok:
+        assert st == M.SolverStatus.Infeasible
+        return None, ns
+    it, oa = ns.internal(), o.internal_arrays()
+    A = o.all_arc_num
+    assert it["search_arc_num"] == o.search_arc_num
+    for k, ok_ in (("source", "src"), ("target", "tgt"), ("cost", "cost"), ("state", "state")):
+        assert np.array_equal(it[k][:A], oa[ok_][:A]), k
+    assert np.array_equal(it["pi"], oa["pi"])
+    n = 0
+    while True:
+        f, e = o.find_entering()
+        if not f:
+            break
+        r = o.apply_pivot(e)
+        unb = ns.apply_pivot(e)
+        assert unb == (r == O.UNBOUNDED)
+        if unb:
+            break
+        lp = ns.last_pivot()
+        assert len(lp["nodes"]) == o.last_subtree and lp["sigma"] == o.last_sigma
+        assert len(set(lp["nodes"].tolist())) == len(lp["nodes"])
+        n += 1
+    st_o = o.finish() if o.status != O.UNBOUNDED and not unb_or(o) else O.UNBOUNDED
+    st = ns.finish()
+    return (o, st_o, n), (ns, st)
+
+
+def unb_or(o):
+    return o.status == O.UNBOUNDED
+
+
+@pytest.mark.parametrize("name", ["netgen_8_08a", "netgen_8_10a", "transport_40x30", "circulation_100_0_10",
+                                  "SimpleProblemIllustration2NonSparse", "assignment_50x50", "grid_5x5", "AURV19V6"])
+def test_sequential_driver_replays_identically(name):
+    """Tree surgery, flows, potentials and the per-pivot device patches of the product equal the oracle's when both are
+    fed the same entering arcs (C# semantics, all rules)."""
+    p = load(name)
+    for sem, rule in [(O.SEM_CSHARP_OPT, O.RULE_BLOCK), (O.SEM_CSHARP, O.RULE_BEST), (O.SEM_CSHARP_OPT, O.RULE_FIRST)]:
+        if p.m > 20000 and rule != O.RULE_BLOCK:
+            continue
+        (o, st_o, n), (ns, st) = _replay(p, sem, rule)
+        assert st == st_o == O.OPTIMAL
+        assert ns.get_total_cost() == o.total_cost
+        assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
+        it, oa = ns.internal(), o.internal_arrays()
+        assert np.array_equal(it["state"][: o.all_arc_num], oa["state"][: o.all_arc_num])
+        assert np.array_equal(it["pi"], oa["pi"])
+        validate_solution(p, ns.flows(), ns.potentials())
+
+
+@pytest.mark.parametrize("kat", K.CSHARP_KATS, ids=[k[0] for k in K.CSHARP_KATS])
+def test_csharp_kats_through_the_host_driver(kat):
+    name, d, status, cost, flows = kat
+    p = problem_from_dict(d)
+    res = _replay(p, O.SEM_CSHARP_OPT, O.RULE_BLOCK)
+    (o, st_o, n), (ns, st) = res
+    assert st == status
+    if status == M.SolverStatus.Optimal:
+        if cost is not None:
+            assert ns.get_total_cost() == cost
+        if flows is not None:
+            assert ns.flows().tolist() == flows
+        for a in range(p.m):
+            assert ns.get_flow(a) == ns.flows()[a]
+    else:
+        with pytest.raises(M.McfError) as ei:       # "Solution not optimal" (NetworkSimplex.cs:418-421)
+            ns.get_total_cost()
+        assert ei.value.code == L.ERR_STATE
+
+
+def test_leq_and_lower_bounds():
+    d = [c for c in K.LEMON_TABLE if c[0] == 3][0]          # balanced supplies, lower bounds l2: cost 5970
+    p = problem_from_dict(d[1])
+    (o, st_o, n), (ns, st) = _replay(p, O.SEM_CSHARP, O.RULE_BEST, supply_type=O.LEQ)
+    assert st == st_o == O.OPTIMAL and ns.get_total_cost() == o.total_cost == 5970
+    assert np.all(ns.flows() >= p.lower)
+    validate_solution(p, ns.flows(), ns.potentials(), supply_type=O.LEQ)
+    # upper bounds are reduced in place by the transformation (D11, NetworkSimplex.cs:649,:519-527)
+    e = int(np.nonzero(p.lower)[0][0])
+    assert ns.get_arc_upper_bound(e) == p.upper[e] - p.lower[e]
+    # D9: with genuine LEQ slack the C# feasibility check (NetworkSimplex.cs:689,:1272-1283) looks at the root links
+    # that carry the slack and answers Infeasible where LEMON finds 5930 -- mirrored, not repaired
+    d = [c for c in K.LEMON_TABLE if c[0] == 20][0]
+    p = problem_from_dict(d[1])
+    (o, st_o, n), (ns, st) = _replay(p, O.SEM_CSHARP, O.RULE_BEST, supply_type=O.LEQ)
+    assert st == st_o == O.INFEASIBLE
+    ol = O.Oracle(p, O.SEM_LEMON, O.RULE_BEST, supply_type=O.LEQ)
+    assert ol.solve()[0] == O.OPTIMAL and ol.total_cost == 5930
+
+
+def test_argument_errors_mirror_the_reference():
+    ns = M.NetworkSimplex(3, [0, 1], [1, 2])
+    for call in (lambda: ns.set_arc_cost(2, 1), lambda: ns.set_arc_bounds(-1, 0, 1), lambda: ns.set_node_supply(3, 1),
+                 lambda: ns.set_pivot_rule(M.PivotRule.CandidateList)):     # NetworkSimplex.cs:155-158,:884
+        with pytest.raises(M.McfError) as ei:
+            call()
+        assert ei.value.code == L.ERR_INVALID
+    with pytest.raises(M.McfError):
+        M.NetworkSimplex(2, [0, 5], [1, 1])
+    with pytest.raises(M.McfError) as ei:
+        ns.apply_pivot(0)           # before begin()
+    assert ei.value.code == L.ERR_STATE
+    assert ns.begin() == 0
+    with pytest.raises(M.McfError):
+        ns.apply_pivot(99)
+    with pytest.raises(M.McfError) as ei:
+        ns.begin()                  # single shot
+    assert ei.value.code == L.ERR_STATE
+
+
+def test_bounds_check_comes_first():
+    ns = M.NetworkSimplex(2, [0], [1]).set_arc_bounds(0, 5, 3).set_node_supply(0, 4).set_node_supply(1, -4)
+    assert ns.begin() == M.SolverStatus.Infeasible
+
+
+def test_generators_are_deterministic_and_feasible():
+    g1 = M.netgen_like(13502460, 2000, 9000, 40, 40)
+    g2 = M.netgen_like(13502460, 2000, 9000, 40, 40)
+    for f in ("source", "target", "lower", "upper", "cost", "supply"):
+        assert np.array_equal(getattr(g1, f), getattr(g2, f))
+    assert g1.node_count == 2000 and g1.arc_count == 9000
+    assert g1.supply.sum() == 0 and g1.supply[:40].sum() == 40 * 1000 and np.all(g1.supply[:40] > 0)
+    assert np.all(g1.supply[-40:] < 0) and np.all(g1.supply[40:-40] == 0)
+    assert np.all(g1.cost >= 1) and np.all(g1.cost <= 10000) and np.all(g1.upper >= 1) and np.all(g1.lower == 0)
+    assert np.all(np.diff(g1.source) >= 0), "arcs are grouped by tail node"
+    assert np.all(g1.source != g1.target)
+    p = O.Problem(g1.node_count, g1.arc_count, g1.source, g1.target, g1.lower, g1.upper, g1.cost, g1.supply)
+    costs = set()
+    for sem, rule in [(O.SEM_CSHARP_OPT, O.RULE_BLOCK), (O.SEM_LEMON, O.RULE_BLOCK), (O.SEM_CSHARP, O.RULE_BEST)]:
+        o = O.Oracle(p, sem, rule)
+        assert o.solve()[0] == O.OPTIMAL
+        costs.add(o.total_cost)
+    assert len(costs) == 1
+    g3 = M.netgen_like(7, 2000, 9000, 40, 40)
+    assert not np.array_equal(g1.cost, g3.cost)
+    a = M.assignment(42, 30)
+    assert a.node_count == 60 and a.arc_count == 900 and a.supply.sum() == 0 and set(a.upper.tolist()) == {1}
+    pa = O.Problem(a.node_count, a.arc_count, a.source, a.target, a.lower, a.upper, a.cost, a.supply)
+    o = O.Oracle(pa, O.SEM_CSHARP_OPT, O.RULE_BEST)
+    assert o.solve()[0] == O.OPTIMAL and o.flow().sum() == 30
+    with pytest.raises(M.McfError):
+        M.netgen_like(1, 100, 50, 10, 10)      # fewer arcs than the skeleton needs
+
+
+def test_dimacs_reader_matches_fixtures_and_roundtrips(tmp_path):
+    for name, path, _ in fixtures():
+        if name not in ("netgen_8_08a", "transport_2x3", "AURV19V6", "grid_5x5", "TablesAreCorrectSimple"):
+            continue
+        a, b = M.read_dimacs(path), load(path)
+        assert (a.node_count, a.arc_count) == (b.n, b.m)
+        for fa, fb in (("source", "src"), ("target", "tgt"), ("lower", "lower"), ("upper", "upper"), ("cost", "cost"), ("supply", "supply")):
+            assert np.array_equal(getattr(a, fa), getattr(b, fb)), (name, fa)
+        out = str(tmp_path / (name + ".min"))
+        M.write_dimacs(a, out)
+        c = M.read_dimacs(out)
+        for f in ("source", "target", "lower", "upper", "cost", "supply"):
+            assert np.array_equal(getattr(a, f), getattr(c, f))
+    with pytest.raises(M.McfError) as ei:
+        M.read_dimacs(str(tmp_path / "missing.min"))
+    assert ei.value.code == L.ERR_IO
+    bad = tmp_path / "bad.min"
+    bad.write_text("p min 2 2\na 1 2 0 1 1\n")
+    with pytest.raises(M.McfError):
+        M.read_dimacs(str(bad))
+    empty = tmp_path / "empty.min"
+    empty.write_text("c nothing\np min 3 0\nn 1 0\n")
+    e = M.read_dimacs(str(empty))
+    assert e.arc_count == 0 and e.node_count == 3
+
+
+def test_shard_ranges_partition_the_search_arcs():
+    for m_s in (0, 1, 3, 4, 5, 1023, 40000, 400001):
+        for world in (1, 2, 3, 8):
+            prev = 0
+            for r in range(world):
+                b, e = M.shard_range(m_s, r, world)
+                assert b == prev and e >= b and b % 4 == 0
+                prev = e
+            assert prev == m_s
+    with pytest.raises(M.McfError):
+        M.shard_range(10, 2, 2)
