@@ -74,12 +74,18 @@ struct ScanParams {
     T pi_val[kInlinePi];
 };
 
+// k = better(o, k) ? o : k, written as per-field selects.  (hipcc 7.2 mis-compiled the whole-struct form
+// `if (better(o, k)) k = o;` in the int64 Block Search kernel: c was updated, p was not -- caught by the parity tests.)
 template <int RULE>
-__device__ __forceinline__ bool better(const Key &a, const Key &b)
+__device__ __forceinline__ void take_if_better(Key &k, int64_t oc, uint32_t orank, uint32_t op)
 {
-    if (RULE == MCF_RULE_BEST_ELIGIBLE) return a.c < b.c || (a.c == b.c && a.p < b.p);
-    if (RULE == MCF_RULE_FIRST_ELIGIBLE) return a.p < b.p;
-    return a.r < b.r || (a.r == b.r && (a.c < b.c || (a.c == b.c && a.p < b.p)));
+    bool take;
+    if (RULE == MCF_RULE_BEST_ELIGIBLE) take = oc < k.c || (oc == k.c && op < k.p);
+    else if (RULE == MCF_RULE_FIRST_ELIGIBLE) take = op < k.p;
+    else take = orank < k.r || (orank == k.r && (oc < k.c || (oc == k.c && op < k.p)));
+    k.c = take ? oc : k.c;
+    k.r = take ? orank : k.r;
+    k.p = take ? op : k.p;
 }
 
 template <int RULE>
@@ -87,11 +93,10 @@ __device__ __forceinline__ Key wave_min(Key k)
 {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-        Key o;
-        o.c = __shfl_xor(k.c, off, 64);
-        o.p = __shfl_xor(k.p, off, 64);
-        o.r = (RULE == MCF_RULE_BLOCK_SEARCH) ? __shfl_xor(k.r, off, 64) : 0u;
-        if (better<RULE>(o, k)) k = o;
+        const int64_t oc = __shfl_xor(k.c, off, 64);
+        const uint32_t op = __shfl_xor(k.p, off, 64);
+        const uint32_t orank = (RULE == MCF_RULE_BLOCK_SEARCH) ? __shfl_xor(k.r, off, 64) : 0u;
+        take_if_better<RULE>(k, oc, orank, op);
     }
     return k;
 }
@@ -142,12 +147,11 @@ __device__ __forceinline__ void scan_tile(const ScanParams<T> &p, int i0, Key &b
             uint32_t pos = pos0 + j;   // the group may straddle the wrap point
             if (pos >= (uint32_t)p.m_s) pos -= (uint32_t)p.m_s;
             if (RULE == MCF_RULE_FIRST_ELIGIBLE) {
-                if (rc < 0 && pos < best.p) { best.p = pos; best.c = rc; }
+                if (rc < 0) take_if_better<RULE>(best, rc, 0u, pos);
             } else {
                 uint32_t r = pos / (uint32_t)p.block_size;
                 r = 2 * r + ((OPT && (int)r == p.rstar && e0 + j < p.next_arc) ? 1u : 0u);
-                Key k{rc, r, pos};
-                if (rc < 0 && better<RULE>(k, best)) best = k;
+                if (rc < 0) take_if_better<RULE>(best, rc, r, pos);
             }
         }
     }
@@ -186,8 +190,7 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(const ScanParams<T> p)
     if (tid == 0) {
         Key k = wave_best[0];
 #pragma unroll
-        for (int w = 1; w < kThreads / 64; ++w)
-            if (better<RULE>(wave_best[w], k)) k = wave_best[w];
+        for (int w = 1; w < kThreads / 64; ++w) take_if_better<RULE>(k, wave_best[w].c, wave_best[w].r, wave_best[w].p);
         uint4 out;
         out.x = (uint32_t)(uint64_t)k.c;
         out.y = (uint32_t)((uint64_t)k.c >> 32);
