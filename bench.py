@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- pivots/s and solve ms of the MI355X network-simplex pivot engine on BASELINE.json's headline workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json configs[2] = NETGEN-like 100 000 nodes / 300 000 arcs (seed 13502460, 316 sources,
+316 sinks), Best-Eligible full-arc scan, int64, behind EnableOptimizedPivot(true).  One "step" = one full
+Solve() pivot loop of that instance with the SoA arc arrays and potentials ALREADY resident in HBM (mcf_ns_prepare runs
+before the timed region); value = pivots performed by all ranks / max-over-ranks wall time of the K steps.
+
+N > 1: the path shards by independent instances (one solve per GPU, seed + rank): no data-path collective, "scaling": "weak".
+The RCCL MINLOC exchange that shards ONE instance's arcs over the GPUs (BASELINE.json configs[4]) is timed separately with
+--sharded-pivots (a bounded number of pivots of the 1M-node / 8M-arc instance) and reported under "sharded".
+
+The JSON line also carries
+  roofline      dominant kernel = the entering-arc scan; achieved = algorithmic bytes per scan (17*m_s + 8*(n+1))
+                / its average device duration, measured in this run with HIP events attached to sampled dispatches on the
+                engine's stream (hipExtLaunchKernelGGL start/stop = dispatch begin..end, what rocprofv3 --kernel-trace reports)
+  cpu_baseline  the CPU oracle (C restatement of the reference, C# semantics) timed on this host, one core, on a bounded
+                sample of the same workload; kind "port" (the C# reference has no toolchain here, LEMON is unbuildable: DESIGN.md)
+  scan_microbench  scan-only kernel durations at larger sizes, where the HBM roofline fraction is adjudicated
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
+SEED = 13502460
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="config3", choices=["config2", "config3", "config4"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-microbench", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline sample")
+    ap.add_argument("--sharded-pivots", type=int, default=0, help="N>1: also time this many pivots of config 5 sharded over RCCL")
+    return ap.parse_args()
+
+
+def workload(name, seed):
+    import mincostflow_amd as M
+    if name == "config2":
+        return (M.netgen_like(seed, 10_000, 30_000, 100, 100), M.PivotRule.BlockSearch, 32,
+                "NETGEN-like 10k nodes / 30k arcs, Block Search, int32")
+    if name == "config4":
+        return (M.assignment(42 + seed - SEED, 1000, 1, 100), M.PivotRule.BestEligible, 64,
+                "assignment 1000x1000 (1M arcs), Best Eligible, int64")
+    return (M.netgen_like(seed, 100_000, 300_000, 316, 316), M.PivotRule.BestEligible, 64,
+            "NETGEN-like 100k nodes / 300k arcs, Best-Eligible full-arc scan, int64")
+
+
+def cpu_baseline(g, rule, budget_s):
+    """Oracle (C port of the reference, EnableOptimizedPivot semantics), same instance and rule, one core."""
+    from oracle import ns_oracle as O
+    p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
+    o = O.Oracle(p, O.SEM_CSHARP_OPT, {0: O.RULE_FIRST, 1: O.RULE_BEST, 2: O.RULE_BLOCK}[rule])
+    o.init()
+    done, ended, t0 = 0, False, time.perf_counter()
+    chunk = 256
+    while not ended and time.perf_counter() - t0 < budget_s:
+        ended, k = o.run_pivots(chunk)
+        done += k
+        chunk = min(chunk * 2, 1 << 16)
+    dt = time.perf_counter() - t0
+    sample = (f"whole solve ({done} pivots)" if ended else f"first {done} pivots of the same solve") + f", {dt:.1f} s of CPU work"
+    return {"value": done / dt, "unit": "pivots/s", "cores": 1, "kind": "port", "sample": sample,
+            "host_cores_available": os.cpu_count(), "us_per_pivot": dt / max(done, 1) * 1e6}
+
+
+def microbench():
+    """Scan-only kernel at sizes where bandwidth, not dispatch latency, decides (SURVEY.md 8d 'scan-only microbenchmark')."""
+    import numpy as np
+
+    import mincostflow_amd as M
+    rng = np.random.default_rng(7)
+    out = []
+    for m_s, n in ((8_000_000, 1_000_001), (64_000_000, 2_001), (64_000_000, 1_000_001)):
+        a = dict(src=rng.integers(0, n, m_s, dtype=np.int32), tgt=rng.integers(0, n, m_s, dtype=np.int32),
+                 cost=rng.integers(-10 ** 4, 10 ** 4, m_s, dtype=np.int64), state=rng.integers(-1, 2, m_s, dtype=np.int8),
+                 pi=rng.integers(-10 ** 9, 1, n, dtype=np.int64))
+        eng = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible, int_width=64)
+        eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+        nbytes = eng.stats()["bytes_per_scan"]
+        warm = eng.bench_scan(reps=20)
+        cold = eng.bench_scan(reps=8, cold=True, flush_bytes=512 << 20)
+        out.append({"arcs": m_s, "nodes": n, "dtype": "i64", "endpoints": "uniform random", "bytes": nbytes,
+                    "warm_us": warm[0] / 1e3, "cold_us": cold[0] / 1e3, "warm_GBs": nbytes / warm[0], "cold_GBs": nbytes / cold[0],
+                    "warm_frac_of_hbm_peak": nbytes / warm[0] / HBM_PEAK_GBS, "cold_frac_of_hbm_peak": nbytes / cold[0] / HBM_PEAK_GBS})
+        del eng, a
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))     # nccl == RCCL on ROCm
+
+    import mincostflow_amd as M
+    if M.device_count() <= local_rank:
+        raise SystemExit("bench.py needs an MI355X: libmcf_hip.so has no CPU path")
+    torch.cuda.set_device(local_rank)
+
+    g, rule, width, desc = workload(args.workload, SEED + rank)
+
+    def new_solver():
+        ns = M.NetworkSimplex.from_problem(g).set_pivot_rule(rule).enable_optimized_pivot(True)
+        ns.set_device(local_rank, width, 0, M.ENGINE_SAMPLE_KERNEL_TIME)
+        return ns.prepare()            # standard form, start basis, engine, upload: arrays resident before the clock starts
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ns = new_solver()
+        assert ns.solve() == M.SolverStatus.Optimal
+        del ns
+    solvers = [new_solver() for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for ns in solvers:
+        st = ns.solve()
+        assert st == M.SolverStatus.Optimal, st
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_max = float(t.item())
+    else:
+        elapsed_max = elapsed
+    barrier()
+
+    mets = [ns.get_metrics() for ns in solvers]
+    cost = solvers[0].get_total_cost()
+    pivots = sum(m["iterations"] for m in mets)
+    if dist is not None:
+        t = torch.tensor([pivots], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        pivots_all = int(t.item())
+    else:
+        pivots_all = pivots
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    e = [m["engine"] for m in mets]
+    timed = sum(x["timed_scans"] for x in e)
+    scan_ns = sum(x["timed_scan_ns"] for x in e) / max(timed, 1)
+    bytes_per_scan = e[0]["bytes_per_scan"]
+    achieved = bytes_per_scan / scan_ns if scan_ns > 0 else 0.0          # bytes/ns == GB/s
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")            # PMC pass (rocprofv3 --pmc), see profiles/README.md
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("hbm_bytes_per_scan")
+    per = lambda k: sum(m[k] for m in mets) / max(pivots, 1)
+    line = {
+        "metric": "pivots/sec + solve ms, NETGEN 100k-node/300k-arc; arc-scan GB/s vs HBM peak",
+        "value": pivots_all / elapsed_max,
+        "unit": "pivots/s",
+        "n_gpus": args.gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed_max / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int64" if width == 64 else "int32",
+        "data": "synthetic",
+        "config": {"workload": desc, "instance": f"netgen_like(seed={SEED}+rank)" if args.workload != "config4" else "assignment(seed 42)",
+                   "pivot_rule": {0: "FirstEligible", 1: "BestEligible", 2: "BlockSearch"}[rule], "semantics": "EnableOptimizedPivot(true)",
+                   "search_arcs": mets[0]["search_arc_num"], "parallelism": "1 solve per GPU" if args.gpus > 1 else "1 GPU"},
+        "solve_ms": sum(m["loop_us"] for m in mets) / len(mets) / 1e3,
+        "solve_ms_incl_setup_and_upload": sum(m["total_solve_us"] for m in mets) / len(mets) / 1e3,
+        "pivots_per_solve": pivots / len(mets),
+        "total_cost": cost,
+        "us_per_pivot": {"total": per("loop_us"), "pivot_search": per("pivot_search_us"), "tree_update": per("tree_update_us"),
+                         "potential_update": per("potential_update_us")},
+        "engine": {"scan_workgroups": e[0]["scan_workgroups"], "inline_update_share": sum(x["inline_updates"] for x in e) / max(pivots, 1),
+                   "separate_update_launches": sum(x["update_launches"] for x in e), "avg_subtree_nodes": per("potential_nodes")},
+        "roofline": {"bound": "hbm", "kernel": "scan_kernel<int64, BestEligible>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": bytes_per_scan,
+                     "avg_kernel_us": scan_ns / 1e3, "timed_launches": timed,
+                     "note": "7.6 MB per scan is smaller than L2+Infinity Cache and an EMPTY dispatch measures ~4 us by the same method; see scan_microbench for bandwidth-bound sizes"},
+    }
+    if not args.no_cpu_baseline and args.gpus == 1:
+        line["cpu_baseline"] = cpu_baseline(g, rule, args.cpu_seconds)
+        if rule != M.PivotRule.BlockSearch:
+            blk = cpu_baseline(g, M.PivotRule.BlockSearch, args.cpu_seconds)
+            line["cpu_baseline_block_search"] = blk       # the reference's default rule, for the cross-rule comparison
+    if not args.no_microbench and args.gpus == 1:
+        line["scan_microbench"] = microbench()
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
