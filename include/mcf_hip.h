@@ -134,6 +134,10 @@ MCF_API int mcf_engine_find_entering_local(mcf_engine *e, mcf_candidate *out);
  * next_arc on THIS engine (every rank calls it with the same gathered array).  *found / *arc as above. */
 MCF_API int mcf_engine_resolve(mcf_engine *e, int32_t count, const mcf_candidate *all, int32_t *found,
                                int32_t *arc, int64_t *reduced_cost);
+/* The same MINLOC + next_arc bookkeeping without an engine (stateless; *next_arc is read and advanced): what every rank
+ * does with the all-gathered records.  block_size 0 = the reference default for the semantics. */
+MCF_API int mcf_resolve_candidates(int32_t rule, int32_t semantics, int32_t search_arc_num, int32_t block_size, int32_t *next_arc,
+                                   int32_t count, const mcf_candidate *all, int32_t *found, int32_t *arc, int64_t *reduced_cost);
 /* contiguous shard of [0, search_arc_num) for rank r of R, aligned to 4 arcs */
 MCF_API int mcf_shard_range(int32_t search_arc_num, int32_t rank, int32_t world, int32_t *begin, int32_t *end);
 

@@ -89,6 +89,8 @@ SIGNATURES = {
     "mcf_engine_find_entering": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
     "mcf_engine_find_entering_local": (C.c_int, [C.c_void_p, _P(Candidate)]),
     "mcf_engine_resolve": (C.c_int, [C.c_void_p, C.c_int32, _P(Candidate), _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
+    "mcf_resolve_candidates": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), C.c_int32, _P(Candidate),
+                                        _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
     "mcf_shard_range": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
     "mcf_engine_get_next_arc": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "mcf_engine_set_next_arc": (C.c_int, [C.c_void_p, C.c_int32]),

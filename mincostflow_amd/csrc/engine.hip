@@ -503,32 +503,61 @@ int local_search(mcf_engine *e, Key *k)
 }
 
 // entering arc, reduced cost and the rule's next_arc from the winning key (host part of the rules)
-void resolve_key(mcf_engine *e, const Key &k, int32_t *found, int32_t *arc, int64_t *rcost)
+void resolve_key_raw(int rule, int semantics, int m_s, int B, int &next_arc, const Key &k, int32_t *found, int32_t *arc, int64_t *rcost)
 {
-    const int m_s = e->d.search_arc_num;
     if (k.p == kNone) { *found = 0; *arc = -1; if (rcost) *rcost = 0; return; }
     *found = 1;
     if (rcost) *rcost = k.c;
-    if (e->d.rule == MCF_RULE_BEST_ELIGIBLE) { *arc = (int32_t)k.p; return; }          // stateless: NS.cs:1644-1667
-    const int na = e->next_arc >= m_s ? 0 : e->next_arc;
+    if (rule == MCF_RULE_BEST_ELIGIBLE) { *arc = (int32_t)k.p; return; }          // stateless: NS.cs:1644-1667
+    const int na = next_arc >= m_s ? 0 : next_arc;
     const int a = (int)(((int64_t)k.p + na) % m_s);
     *arc = a;
-    if (e->d.rule == MCF_RULE_FIRST_ELIGIBLE) { e->next_arc = a + 1; return; }          // NS.cs:1617, BSPO.cs:199
-    const int B = e->block_size;
+    if (rule == MCF_RULE_FIRST_ELIGIBLE) { next_arc = a + 1; return; }             // NS.cs:1617, BSPO.cs:199
     const int64_t r = k.p / B, boundary = (r + 1) * (int64_t)B - 1;   // scan position of the block's last arc
-    if (e->d.semantics != MCF_SEM_OPTIMIZED) {
+    if (semantics != MCF_SEM_OPTIMIZED) {
         // NS.cs:1358-1397: stop at the boundary -> next_arc = that arc; cycle exhausted first -> unchanged
-        if (boundary <= m_s - 1) e->next_arc = (int)((boundary + na) % m_s);
+        if (boundary <= m_s - 1) next_arc = (int)((boundary + na) % m_s);
         return;
     }
     // BSPO.cs:49-63,98-103: first range [next_arc, m_s), wrapped range [0, next_arc) only if nothing was found
-    const int64_t len1 = e->next_arc >= m_s ? 0 : m_s - e->next_arc;
-    if (a >= e->next_arc && e->next_arc < m_s) {
-        e->next_arc = boundary < len1 ? (int)(e->next_arc + boundary + 1) : m_s;
+    const int64_t len1 = next_arc >= m_s ? 0 : m_s - next_arc;
+    if (a >= next_arc && next_arc < m_s) {
+        next_arc = boundary < len1 ? (int)(next_arc + boundary + 1) : m_s;
     } else {
-        if (boundary < m_s) e->next_arc = (int)(boundary - len1 + 1);
+        if (boundary < m_s) next_arc = (int)(boundary - len1 + 1);
         /* else: the range ended first, ProcessArcRange returns `end` = the old next_arc */
     }
+}
+
+void resolve_key(mcf_engine *e, const Key &k, int32_t *found, int32_t *arc, int64_t *rcost)
+{
+    resolve_key_raw(e->d.rule, e->d.semantics, e->d.search_arc_num, e->block_size, e->next_arc, k, found, arc, rcost);
+}
+
+// MINLOC over the shards' candidates with the rule's ordering
+Key merge_candidates(int rule, int semantics, int m_s, int B, int next_arc, int count, const mcf_candidate *all)
+{
+    const bool block_rule = rule == MCF_RULE_BLOCK_SEARCH, best_rule = rule == MCF_RULE_BEST_ELIGIBLE;
+    int rstar = -1;
+    if (block_rule && semantics == MCF_SEM_OPTIMIZED && next_arc < m_s) {
+        const int len1 = m_s - next_arc;
+        if (len1 % B) rstar = len1 / B;
+    }
+    Key best{0, kNone, kNone};
+    for (int i = 0; i < count; ++i) {
+        if (all[i].pos == kNone) continue;
+        Key k{all[i].reduced_cost, 0, all[i].pos};
+        bool take;
+        if (best_rule) take = best.p == kNone || k.c < best.c || (k.c == best.c && k.p < best.p);
+        else if (!block_rule) take = k.p < best.p;
+        else {
+            const uint32_t r = k.p / (uint32_t)B;
+            k.r = 2 * r + ((rstar >= 0 && (int)r == rstar && all[i].arc < next_arc) ? 1u : 0u);
+            take = best.p == kNone || k.r < best.r || (k.r == best.r && (k.c < best.c || (k.c == best.c && k.p < best.p)));
+        }
+        if (take) best = k;
+    }
+    return best;
 }
 
 }  // namespace
@@ -788,27 +817,22 @@ int mcf_engine_find_entering_local(mcf_engine *e, mcf_candidate *out)
 int mcf_engine_resolve(mcf_engine *e, int32_t count, const mcf_candidate *all, int32_t *found, int32_t *arc, int64_t *reduced_cost)
 {
     if (!e || count < 0 || (count && !all) || !found || !arc) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_resolve: bad arguments");
-    const bool block_rule = e->d.rule == MCF_RULE_BLOCK_SEARCH, best_rule = e->d.rule == MCF_RULE_BEST_ELIGIBLE;
-    int rstar = -1;
-    if (block_rule && e->d.semantics == MCF_SEM_OPTIMIZED && e->next_arc < e->d.search_arc_num) {
-        const int len1 = e->d.search_arc_num - e->next_arc;
-        if (len1 % e->block_size) rstar = len1 / e->block_size;
-    }
-    Key best{0, kNone, kNone};
-    for (int i = 0; i < count; ++i) {
-        if (all[i].pos == kNone) continue;
-        Key k{all[i].reduced_cost, 0, all[i].pos};
-        bool take;
-        if (best_rule) take = best.p == kNone || k.c < best.c || (k.c == best.c && k.p < best.p);
-        else if (!block_rule) take = k.p < best.p;
-        else {
-            const uint32_t r = k.p / (uint32_t)e->block_size;
-            k.r = 2 * r + ((rstar >= 0 && (int)r == rstar && all[i].arc < e->next_arc) ? 1u : 0u);
-            take = best.p == kNone || k.r < best.r || (k.r == best.r && (k.c < best.c || (k.c == best.c && k.p < best.p)));
-        }
-        if (take) best = k;
-    }
+    const Key best = merge_candidates(e->d.rule, e->d.semantics, e->d.search_arc_num, e->block_size, e->next_arc, count, all);
     resolve_key(e, best, found, arc, reduced_cost);
+    return MCF_OK;
+}
+
+int mcf_resolve_candidates(int32_t rule, int32_t semantics, int32_t search_arc_num, int32_t block_size, int32_t *next_arc,
+                           int32_t count, const mcf_candidate *all, int32_t *found, int32_t *arc, int64_t *reduced_cost)
+{
+    if (!next_arc || count < 0 || (count && !all) || !found || !arc || rule < 0 || rule > 2 || search_arc_num < 0 ||
+        (semantics != MCF_SEM_PLAIN && semantics != MCF_SEM_OPTIMIZED) || *next_arc < 0 || *next_arc > search_arc_num)
+        return mcf::fail(MCF_ERR_INVALID, "mcf_resolve_candidates: bad arguments");
+    const int B = block_size > 0 ? block_size : mcf::default_block_size(search_arc_num, semantics);
+    const Key best = merge_candidates(rule, semantics, search_arc_num, B, *next_arc, count, all);
+    int na = *next_arc;
+    resolve_key_raw(rule, semantics, search_arc_num, B, na, best, found, arc, reduced_cost);
+    *next_arc = na;
     return MCF_OK;
 }
 

@@ -300,3 +300,12 @@ def shard_range(search_arc_num: int, rank: int, world: int):
     b, e = C.c_int32(), C.c_int32()
     L.check(L.lib().mcf_shard_range(search_arc_num, rank, world, C.byref(b), C.byref(e)))
     return b.value, e.value
+
+
+def resolve_candidates(rule: int, optimized: bool, search_arc_num: int, block_size: int, next_arc: int, cands):
+    """Engine-free MINLOC over per-shard candidates; returns (found, arc, reduced_cost, new_next_arc)."""
+    arr = (L.Candidate * len(cands))(*cands)
+    na, f, a, c = C.c_int32(next_arc), C.c_int32(), C.c_int32(), C.c_int64()
+    L.check(L.lib().mcf_resolve_candidates(rule, L.SEM_OPTIMIZED if optimized else L.SEM_PLAIN, search_arc_num, block_size,
+                                           C.byref(na), len(cands), arr, C.byref(f), C.byref(a), C.byref(c)))
+    return bool(f.value), a.value, c.value, na.value

@@ -1,0 +1,108 @@
+"""N > 1 path on CPU: two `gloo` ranks each own an arc shard, exchange their 16-byte candidates with an all-gather,
+resolve the global entering arc with the product's MINLOC (mcf_resolve_candidates) and drive replicated copies of the
+product's sequential host driver.  The only thing that is not product code is the per-shard reduced-cost scan, done here
+with numpy / the oracle because there is no GPU (on the GPU box that scan is mcf_engine_find_entering_local and the
+exchange is one ncclAllGather: mcf_engine_find_entering_sharded)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NONE = 0xFFFFFFFF
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _local_candidate(M, L, a, m_s, shard, rule, optimized, block, next_arc):
+    """Best candidate of arcs [b, e) under the rule's ordering: numpy restatement of the kernel's per-shard result."""
+    b, e = shard
+    cand = L.Candidate(0, NONE, -1)
+    if e <= b:
+        return cand
+    idx = np.arange(b, e)
+    rc = a["state"][b:e].astype(np.int64) * (a["cost"][b:e] + a["pi"][a["source"][b:e]] - a["pi"][a["target"][b:e]])
+    elig = rc < 0
+    if not elig.any():
+        return cand
+    idx, rc = idx[elig], rc[elig]
+    if rule == M.PivotRule.BestEligible:
+        k = np.lexsort((idx, rc))[0]
+        return L.Candidate(int(rc[k]), int(idx[k]), int(idx[k]))
+    na = 0 if next_arc >= m_s else next_arc
+    pos = (idx - na) % m_s
+    if rule == M.PivotRule.FirstEligible:
+        k = int(np.argmin(pos))
+        return L.Candidate(int(rc[k]), int(pos[k]), int(idx[k]))
+    r = pos // block
+    rank = 2 * r
+    if optimized and next_arc < m_s and (m_s - next_arc) % block:
+        rstar = (m_s - next_arc) // block
+        rank = rank + ((r == rstar) & (idx < next_arc))
+    k = np.lexsort((pos, rc, rank))[0]
+    return L.Candidate(int(rc[k]), int(pos[k]), int(idx[k]))
+
+
+def _rank_main(rank, world, port, fixture, rule, optimized, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import mincostflow_amd as M
+    from helpers import load
+    from mincostflow_amd import _lib as L
+    from oracle import ns_oracle as O
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = load(fixture)
+    ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
+    assert ns.begin() == 0
+    m_s = ns.internal()["search_arc_num"]
+    shard = M.shard_range(m_s, rank, world)
+    block = max(int(np.sqrt(m_s)), 10)
+    next_arc, trace = 0, []
+    while True:
+        a = ns.internal()
+        mine = _local_candidate(M, L, a, m_s, shard, rule, optimized, block, next_arc)
+        send = torch.frombuffer(bytearray(bytes(mine)), dtype=torch.uint8)          # the 16-byte mcf_candidate record
+        got = [torch.zeros(16, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(got, send)
+        cands = [L.Candidate.from_buffer_copy(bytes(t.numpy().tobytes())) for t in got]
+        found, arc, rc, next_arc = M.resolve_candidates(rule, optimized, m_s, block, next_arc, cands)
+        if not found:
+            break
+        trace.append(arc)
+        assert not ns.apply_pivot(arc)
+    status = ns.finish()
+    # the reference answer: one un-sharded oracle solve with the same rule
+    o = O.Oracle(p, O.SEM_CSHARP_OPT if optimized else O.SEM_CSHARP, {0: O.RULE_FIRST, 1: O.RULE_BEST, 2: O.RULE_BLOCK}[rule], block_size=block)
+    st_o, tr_o = o.solve(trace_cap=1 << 22)
+    assert status == st_o == 1
+    assert np.array_equal(np.array(trace, np.int32), tr_o), "sharded pivot sequence differs from the single-rank one"
+    assert ns.get_total_cost() == o.total_cost and np.array_equal(ns.flows(), o.flow())
+    # replicated host state must be identical on all ranks
+    digest = torch.tensor([ns.get_total_cost(), int(ns.potentials().sum()), len(trace)], dtype=torch.int64)
+    all_d = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(all_d, digest)
+    assert all(torch.equal(all_d[0], d) for d in all_d)
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write(str(len(trace)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fixture,rule,optimized", [("netgen_8_08a", 1, True), ("netgen_8_08a", 2, True), ("transport_40x30", 2, False),
+                                                    ("circulation_100_0_10", 0, True)])
+def test_two_rank_sharded_solve_over_gloo(tmp_path, fixture, rule, optimized):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_rank_main, args=(world, port, fixture, rule, optimized, str(tmp_path)), nprocs=world, join=True)
+    counts = [int(open(tmp_path / f"ok{r}").read()) for r in range(world)]
+    assert counts[0] == counts[1] > 0
