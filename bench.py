@@ -14,9 +14,12 @@ The RCCL MINLOC exchange that shards ONE instance's arcs over the GPUs (BASELINE
 --sharded-pivots (a bounded number of pivots of the 1M-node / 8M-arc instance) and reported under "sharded".
 
 The JSON line also carries
-  roofline      dominant kernel = the entering-arc scan; achieved = algorithmic bytes per scan (17*m_s + 8*(n+1))
-                / its average device duration, measured in this run with HIP events attached to sampled dispatches on the
-                engine's stream (hipExtLaunchKernelGGL start/stop = dispatch begin..end, what rocprofv3 --kernel-trace reports)
+  roofline      dominant kernel = the resident entering-arc scan grid (one dispatch serves every pivot of a solve through a mailbox).
+                achieved = algorithmic bytes per launch (requests served x (17*m_s + 8*(n+1))) / the launch's duration,
+                measured in this run with HIP events attached to the dispatch on the engine's stream (hipExtLaunchKernelGGL start/stop =
+                dispatch begin..end, what rocprofv3 --kernel-trace reports).  The grid waits for the host between requests, so this is
+                the END-TO-END figure; "in_kernel" (device clock, request seen -> record published) and "scan_dispatch" (the same scan as
+                one dispatch per search, timed alone) isolate the scan itself.
   cpu_baseline  the CPU oracle (C restatement of the reference, C# semantics) timed on this host, one core, on a bounded
                 sample of the same workload; kind "port" (the C# reference has no toolchain here, LEMON is unbuildable: DESIGN.md)
   scan_microbench  scan-only kernel durations at larger sizes, where the HBM roofline fraction is adjudicated
@@ -45,6 +48,7 @@ def parse():
     ap.add_argument("--no-microbench", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline sample")
     ap.add_argument("--sharded-pivots", type=int, default=0, help="N>1: also time this many pivots of config 5 sharded over RCCL")
+    ap.add_argument("--dispatch", action="store_true", help="one scan dispatch per search instead of the resident grid")
     return ap.parse_args()
 
 
@@ -125,7 +129,7 @@ def main():
 
     def new_solver():
         ns = M.NetworkSimplex.from_problem(g).set_pivot_rule(rule).enable_optimized_pivot(True)
-        ns.set_device(local_rank, width, 0, M.ENGINE_SAMPLE_KERNEL_TIME)
+        ns.set_device(local_rank, width, 0, (M.ENGINE_DISPATCH | M.ENGINE_SAMPLE_KERNEL_TIME) if args.dispatch else 0)
         return ns.prepare()            # standard form, start basis, engine, upload: arrays resident before the clock starts
 
     def barrier():
@@ -169,10 +173,39 @@ def main():
         return
 
     e = [m["engine"] for m in mets]
-    timed = sum(x["timed_scans"] for x in e)
-    scan_ns = sum(x["timed_scan_ns"] for x in e) / max(timed, 1)
     bytes_per_scan = e[0]["bytes_per_scan"]
-    achieved = bytes_per_scan / scan_ns if scan_ns > 0 else 0.0          # bytes/ns == GB/s
+    resident = bool(e[0]["resident"])
+    if resident:
+        launches = sum(x["resident_launches"] for x in e)
+        requests = sum(x["resident_requests"] for x in e)
+        kernel_ns = sum(x["resident_kernel_ns"] for x in e)
+        bytes_per_launch = bytes_per_scan * requests / max(launches, 1)
+        avg_launch_ns = kernel_ns / max(launches, 1)
+        achieved = bytes_per_launch / avg_launch_ns if avg_launch_ns > 0 else 0.0       # bytes/ns == GB/s
+        in_kernel_ns = sum(x["resident_scan_ns"] for x in e) / max(requests, 1)
+        kernel_name = "resident_kernel<int64, BestEligible, REG>"
+        extra = {"launches": launches, "requests_per_launch": requests / max(launches, 1), "avg_launch_ms": avg_launch_ns / 1e6,
+                 "in_kernel": {"avg_request_us": in_kernel_ns / 1e3, "achieved": bytes_per_scan / in_kernel_ns if in_kernel_ns > 0 else 0.0,
+                               "frac": bytes_per_scan / in_kernel_ns / HBM_PEAK_GBS if in_kernel_ns > 0 else 0.0,
+                               "what": "device clock (s_memrealtime), workgroup 0: request seen -> 16-byte record published; includes fetching and applying the patch list"}}
+    else:
+        timed = sum(x["timed_scans"] for x in e)
+        scan_ns = sum(x["timed_scan_ns"] for x in e) / max(timed, 1)
+        bytes_per_launch = bytes_per_scan
+        achieved = bytes_per_scan / scan_ns if scan_ns > 0 else 0.0
+        kernel_name = "scan_kernel<int64, BestEligible>"
+        extra = {"avg_kernel_us": scan_ns / 1e3, "timed_launches": timed}
+    # the same scan as a stand-alone dispatch on the same arrays (HIP events, 200 repetitions, warm)
+    it0 = solvers[0].internal()
+    eng = M.PivotEngine(g.node_count + 1, it0["search_arc_num"], it0["search_arc_num"], rule=rule, optimized=True, int_width=width,
+                        device=local_rank, flags=M.ENGINE_DISPATCH)
+    ms = it0["search_arc_num"]
+    eng.upload(it0["source"][:ms], it0["target"][:ms], it0["cost"][:ms], it0["state"][:ms], it0["pi"])
+    d_avg, d_min = eng.bench_scan(reps=200)
+    del eng
+    extra["scan_dispatch"] = {"avg_kernel_us": d_avg / 1e3, "min_kernel_us": d_min / 1e3, "achieved": bytes_per_scan / d_avg,
+                              "frac": bytes_per_scan / d_avg / HBM_PEAK_GBS,
+                              "what": "scan_kernel as one dispatch per search, timed alone with HIP events; an EMPTY dispatch measures ~4 us by this method"}
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")            # PMC pass (rocprofv3 --pmc), see profiles/README.md
     if os.path.exists(tpath):
@@ -200,12 +233,12 @@ def main():
         "total_cost": cost,
         "us_per_pivot": {"total": per("loop_us"), "pivot_search": per("pivot_search_us"), "tree_update": per("tree_update_us"),
                          "potential_update": per("potential_update_us")},
-        "engine": {"scan_workgroups": e[0]["scan_workgroups"], "inline_update_share": sum(x["inline_updates"] for x in e) / max(pivots, 1),
+        "engine": {"mode": "resident grid + BAR mailbox" if resident else "one dispatch per search", "scan_workgroups": e[0]["scan_workgroups"], "inline_update_share": sum(x["inline_updates"] for x in e) / max(pivots, 1),
                    "separate_update_launches": sum(x["update_launches"] for x in e), "avg_subtree_nodes": per("potential_nodes")},
-        "roofline": {"bound": "hbm", "kernel": "scan_kernel<int64, BestEligible>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": bytes_per_scan,
-                     "avg_kernel_us": scan_ns / 1e3, "timed_launches": timed,
-                     "note": "7.6 MB per scan is smaller than L2+Infinity Cache and an EMPTY dispatch measures ~4 us by the same method; see scan_microbench for bandwidth-bound sizes"},
+        "roofline": dict({"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": bytes_per_launch,
+                          "note": "7.6 MB per scan lives in L2 / Infinity Cache and the per-pivot cost is host <-> device latency, not bandwidth; "
+                                  "scan_microbench holds the bandwidth-bound sizes"}, **extra),
     }
     if not args.no_cpu_baseline and args.gpus == 1:
         line["cpu_baseline"] = cpu_baseline(g, rule, args.cpu_seconds)

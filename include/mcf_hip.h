@@ -97,6 +97,11 @@ typedef struct mcf_engine_desc {
 #define MCF_ENGINE_SAMPLE_KERNEL_TIME 1   /* time every 16th scan dispatch with HIP events */
 #define MCF_ENGINE_TIME_EVERY_KERNEL 2    /* time every scan dispatch (micro-benchmarks) */
 #define MCF_ENGINE_NO_INLINE_UPDATE 4     /* always apply patches with the separate update kernel */
+#define MCF_ENGINE_RESIDENT 8             /* (default behaviour, kept for explicitness) serve searches from ONE resident scan grid fed
+                                             through a mailbox in BAR-mapped VRAM instead of one dispatch per search */
+#define MCF_ENGINE_DISPATCH 16            /* one scan dispatch per search.  Also what an engine falls back to when it is sharded, when
+                                             kernel timing flags are set, or when the platform has no host-writable VRAM.
+                                             The environment variable MCF_HIP_RESIDENT=0/1 overrides the choice. */
 
 /* replaces the constructor of OptimizedPivotWrapper (NS.cs:1677-1697) */
 MCF_API int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc);
@@ -113,6 +118,10 @@ MCF_API int mcf_engine_patch_state(mcf_engine *e, int32_t count, const int32_t *
 /* UpdatePotentials (NS.cs:1185-1209): pi[nodes[i]] += sigma.  The caller walks the thread list (it owns the tree);
  * nodes must be distinct.  Queued; ordered before the next search. */
 MCF_API int mcf_engine_update_potential(mcf_engine *e, int32_t count, const int32_t *nodes, int64_t sigma);
+
+/* Same as update_potential for callers that already hold the new values (the C++ host driver does: it keeps _pi itself):
+ * pi[nodes[i]] = values[i]. */
+MCF_API int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values);
 
 /* Rewrites (source, target, cost) of arcs, e.g. artificial arcs re-pointed by a warm start. Synchronous. */
 MCF_API int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, const int32_t *source,
@@ -141,6 +150,8 @@ MCF_API int mcf_resolve_candidates(int32_t rule, int32_t semantics, int32_t sear
 /* contiguous shard of [0, search_arc_num) for rank r of R, aligned to 4 arcs */
 MCF_API int mcf_shard_range(int32_t search_arc_num, int32_t rank, int32_t world, int32_t *begin, int32_t *end);
 
+/* Stops a running resident grid (it restarts with the next search).  Call before device-wide synchronisation. */
+MCF_API int mcf_engine_park(mcf_engine *e);
 MCF_API int mcf_engine_get_next_arc(mcf_engine *e, int32_t *next_arc);
 MCF_API int mcf_engine_set_next_arc(mcf_engine *e, int32_t next_arc);
 MCF_API int mcf_engine_get_block_size(mcf_engine *e, int32_t *block_size);
@@ -162,6 +173,11 @@ typedef struct mcf_engine_stats {
     double host_launch_ns;        /* host time spent inside launch calls */
     int32_t scan_workgroups, scan_threads;
     int64_t bytes_per_scan;       /* algorithmic bytes of one scan: SURVEY.md 8d */
+    int64_t resident;             /* 1 when the engine runs in resident mode */
+    int64_t resident_launches;    /* dispatches of the resident grid */
+    int64_t resident_requests;    /* searches it served */
+    double resident_scan_ns;      /* device clock: request seen -> record published, workgroup 0, summed over requests */
+    double resident_kernel_ns;    /* HIP-event residency time of those dispatches */
 } mcf_engine_stats;
 MCF_API int mcf_engine_get_stats(mcf_engine *e, mcf_engine_stats *out);
 MCF_API int mcf_engine_reset_stats(mcf_engine *e);

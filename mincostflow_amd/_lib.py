@@ -20,7 +20,7 @@ SUPPLY_GEQ, SUPPLY_LEQ = 0, 1
 NOT_SOLVED, OPTIMAL, INFEASIBLE, UNBOUNDED, UNBALANCED = 0, 1, 2, 3, 4
 STATE_UPPER, STATE_TREE, STATE_LOWER = -1, 0, 1
 INF_CAP = np.iinfo(np.int64).max
-ENGINE_SAMPLE_KERNEL_TIME, ENGINE_TIME_EVERY_KERNEL, ENGINE_NO_INLINE_UPDATE = 1, 2, 4
+ENGINE_SAMPLE_KERNEL_TIME, ENGINE_TIME_EVERY_KERNEL, ENGINE_NO_INLINE_UPDATE, ENGINE_RESIDENT, ENGINE_DISPATCH = 1, 2, 4, 8, 16
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OVERFLOW, ERR_TIMEOUT, ERR_STATE, ERR_IO, ERR_COMM = -1, -2, -3, -4, -5, -6, -7, -8
 
 
@@ -44,7 +44,8 @@ class EngineStats(C.Structure):
                 ("inline_updates", C.c_int64), ("potential_nodes", C.c_int64), ("arcs_scanned", C.c_int64),
                 ("timed_scans", C.c_int64), ("timed_scan_ns", C.c_double), ("host_wait_ns", C.c_double),
                 ("host_launch_ns", C.c_double), ("scan_workgroups", C.c_int32), ("scan_threads", C.c_int32),
-                ("bytes_per_scan", C.c_int64)]
+                ("bytes_per_scan", C.c_int64), ("resident", C.c_int64), ("resident_launches", C.c_int64),
+                ("resident_requests", C.c_int64), ("resident_scan_ns", C.c_double), ("resident_kernel_ns", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -85,6 +86,7 @@ SIGNATURES = {
     "mcf_engine_upload": (C.c_int, [C.c_void_p, _i32p, _i32p, _i64p, _i8p, _i64p]),
     "mcf_engine_patch_state": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i8p]),
     "mcf_engine_update_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, C.c_int64]),
+    "mcf_engine_set_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i64p]),
     "mcf_engine_patch_arcs": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, _i64p]),
     "mcf_engine_find_entering": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
     "mcf_engine_find_entering_local": (C.c_int, [C.c_void_p, _P(Candidate)]),
@@ -92,6 +94,7 @@ SIGNATURES = {
     "mcf_resolve_candidates": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), C.c_int32, _P(Candidate),
                                         _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
     "mcf_shard_range": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
+    "mcf_engine_park": (C.c_int, [C.c_void_p]),
     "mcf_engine_get_next_arc": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "mcf_engine_set_next_arc": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_engine_get_block_size": (C.c_int, [C.c_void_p, _P(C.c_int32)]),

@@ -15,6 +15,8 @@
 // bandwidth / latency.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 
 #include <dlfcn.h>
 #include <immintrin.h>
@@ -32,7 +34,7 @@ namespace {
 constexpr int kThreads = 256;              // 4 wavefronts of 64
 constexpr int kArcsPerThread = 4;          // 16-byte loads of source/target, 4-byte load of state
 constexpr int kTile = kThreads * kArcsPerThread;   // 1024 arcs per workgroup per step
-constexpr int kPad = 2 * kTile;            // device arrays are padded to this with state = 0
+constexpr int kPad = 4 * kTile;            // device arrays are padded to this with state = 0 (one resident workgroup = 4096 arcs)
 constexpr int kInlinePi = 96;              // potentials patched through the kernel arguments
 constexpr int kInlineState = 4;
 constexpr int kMaxWorkgroups = 2048;
@@ -115,45 +117,88 @@ template <> struct Vec4<int64_t> {
     }
 };
 
-// One tile = 1024 consecutive arcs, 4 per thread.  All loads of a tile are issued before any use.
-template <typename T, int RULE, bool OPT>
-__device__ __forceinline__ void scan_tile(const ScanParams<T> &p, int i0, Key &best)
-{
-    const uint32_t st4 = *reinterpret_cast<const uint32_t *>(p.state + i0);
+// One tile = 1024 consecutive arcs, 4 per thread.  load_tile issues all of a thread's streamed loads; eval_tile gathers the
+// eight potentials and folds the four reduced costs into the running key.  (The resident kernel loads once and evaluates
+// every pivot.)
+template <typename T>
+struct TileData {
+    uint32_t st4;
     Vec4<int32_t> s, t;
     Vec4<T> c;
-    s.load(p.src + i0);
-    t.load(p.tgt + i0);
-    c.load(p.cost + i0);
+};
+
+template <typename T>
+__device__ __forceinline__ void load_tile(const int32_t *src, const int32_t *tgt, const T *cost, const int8_t *state, int i0, TileData<T> &d)
+{
+    d.st4 = *reinterpret_cast<const uint32_t *>(state + i0);
+    d.s.load(src + i0);
+    d.t.load(tgt + i0);
+    d.c.load(cost + i0);
+}
+
+template <typename T, int RULE, bool OPT>
+__device__ __forceinline__ void eval_tile(const TileData<T> &d, const T *pi, int e0, int m_s, int next_arc, int block_size, int rstar, Key &best)
+{
     T ps[4], pt[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { ps[j] = p.pi[s.v[j]]; pt[j] = p.pi[t.v[j]]; }
+    for (int j = 0; j < 4; ++j) { ps[j] = pi[d.s.v[j]]; pt[j] = pi[d.t.v[j]]; }
     uint32_t pos0 = 0;
-    const int e0 = p.base + i0;
     if (RULE != MCF_RULE_BEST_ELIGIBLE) {
-        int d = e0 - p.next_arc;
-        if (d < 0) d += p.m_s;
-        pos0 = (uint32_t)d;
+        int q = e0 - next_arc;
+        if (q < 0) q += m_s;
+        pos0 = (uint32_t)q;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int st = (int)(int8_t)(st4 >> (8 * j));
+        const int st = (int)(int8_t)(d.st4 >> (8 * j));
         // 64-bit arithmetic in both widths: int32 inputs cannot overflow it
-        const int64_t d = (int64_t)c.v[j] + (int64_t)ps[j] - (int64_t)pt[j];
-        const int64_t rc = st > 0 ? d : (st < 0 ? -d : 0);
+        const int64_t dd = (int64_t)d.c.v[j] + (int64_t)ps[j] - (int64_t)pt[j];
+        const int64_t rc = st > 0 ? dd : (st < 0 ? -dd : 0);
         if (RULE == MCF_RULE_BEST_ELIGIBLE) {
             if (rc < best.c) { best.c = rc; best.p = (uint32_t)(e0 + j); }   // strict <: lowest arc wins ties
         } else {
             uint32_t pos = pos0 + j;   // the group may straddle the wrap point
-            if (pos >= (uint32_t)p.m_s) pos -= (uint32_t)p.m_s;
+            if (pos >= (uint32_t)m_s) pos -= (uint32_t)m_s;
             if (RULE == MCF_RULE_FIRST_ELIGIBLE) {
                 if (rc < 0) take_if_better<RULE>(best, rc, 0u, pos);
             } else {
-                uint32_t r = pos / (uint32_t)p.block_size;
-                r = 2 * r + ((OPT && (int)r == p.rstar && e0 + j < p.next_arc) ? 1u : 0u);
+                uint32_t r = pos / (uint32_t)block_size;
+                r = 2 * r + ((OPT && (int)r == rstar && e0 + j < next_arc) ? 1u : 0u);
                 if (rc < 0) take_if_better<RULE>(best, rc, r, pos);
             }
         }
+    }
+}
+
+template <typename T, int RULE, bool OPT>
+__device__ __forceinline__ void scan_tile(const ScanParams<T> &p, int i0, Key &best)
+{
+    TileData<T> d;
+    load_tile<T>(p.src, p.tgt, p.cost, p.state, i0, d);
+    eval_tile<T, RULE, OPT>(d, p.pi, p.base + i0, p.m_s, p.next_arc, p.block_size, p.rstar, best);
+}
+
+// workgroup-level finish: wave butterfly -> LDS -> one 16-byte record.  SYSTEM = write-through store for kernels that keep running.
+template <int RULE, bool SYSTEM, int NT = kThreads>
+__device__ __forceinline__ void publish_best(Key best, Slot *slot, uint32_t tag)
+{
+    const int tid = threadIdx.x;
+    best = wave_min<RULE>(best);
+    __shared__ Key wave_best[NT / 64];
+    if ((tid & 63) == 0) wave_best[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        Key k = wave_best[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) take_if_better<RULE>(k, wave_best[w].c, wave_best[w].r, wave_best[w].p);
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        v4u out;
+        out.x = (uint32_t)(uint64_t)k.c;
+        out.y = (uint32_t)((uint64_t)k.c >> 32);
+        out.z = k.p;
+        out.w = tag;
+        if (SYSTEM) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(slot), "v"(out) : "memory");
+        else *reinterpret_cast<v4u *>(slot) = out;
     }
 }
 
@@ -182,21 +227,173 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(const ScanParams<T> p)
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) scan_tile<T, RULE, OPT>(p, i0 + u * kTile, best);
     }
+    publish_best<RULE, false>(best, p.slots + blockIdx.x, p.seq);
+}
 
-    best = wave_min<RULE>(best);
-    __shared__ Key wave_best[kThreads / 64];
-    if ((tid & 63) == 0) wave_best[tid >> 6] = best;
-    __syncthreads();
-    if (tid == 0) {
-        Key k = wave_best[0];
+// ------------------------------------------------------------------------------------------------ resident mode
+// One dispatch per pivot costs ~6.5 us of launch + dispatch latency before any arc is read (profiles/r01_dispatch_floor_kfloor.txt).
+// resident_kernel is launched once and then serves one request per pivot through a MAILBOX in fine-grained VRAM that the host
+// writes through the PCIe BAR: the host posts {seq, next_arc, patches}, every workgroup sees the new seq by polling device
+// memory, applies the patches, scans the tile(s) it owns and answers with its 16-byte record in pinned host memory.
+// Workgroups that own a single tile keep its arcs in registers (REG), so a request costs two potential gathers per arc and nothing else.
+//
+// Mailbox: 64 lines of 64 bytes; dword 15 of EVERY line repeats seq, so a torn read of any line is detected and retried.
+//   line 0      [0] seq [1] cmd (0 scan, 1 quit) [2] next_arc [3] rstar [4] n_pi [5] n_st [6+2k] state arc k [7+2k] state value k
+//   line 1..63  five patches {node, value lo, value hi} each
+// Every spin is bounded by s_memrealtime (100 MHz): a resident grid that hears nothing for idle_ticks exits by itself.
+constexpr int kMailboxLines = 1024;               // lines staged in LDS at a time: 64 KB = line 0 + a chunk of 1023 patch lines (5115 patches)
+constexpr int kMailboxPatchesPerLine = 5;
+constexpr int kChunkLines = kMailboxLines - 1;
+constexpr int kResidentMaxState = 2;
+constexpr int kResidentThreads = 1024;                                          // 16 wavefronts: few pollers, few records
+constexpr int kResidentTile = kResidentThreads * kArcsPerThread;                // 4096 arcs per workgroup
+
+template <typename T>
+struct ResidentParams {
+    const int32_t *src;
+    const int32_t *tgt;
+    const T *cost;
+    int8_t *state;
+    T *pi;
+    Slot *slots;
+    const uint32_t *mailbox;    // fine-grained VRAM, written by the host through the BAR
+    uint32_t *exit_word;        // pinned host memory: [0] exit code, [1] requests served, [2..3] scan ticks of workgroup 0
+    int32_t base, count_padded, m_s, block_size;
+    uint32_t start_seq, idle_ticks;
+    int32_t max_pi;             // patches the mailbox can hold (= node_count)
+};
+
+__device__ __forceinline__ void mailbox_load16(const uint32_t *src, uint32_t *lds_dst)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    v4u x;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(src) : "memory");
+    *reinterpret_cast<v4u *>(lds_dst) = x;
+}
+
+__device__ __forceinline__ void resident_exit(uint32_t *exit_word, uint32_t code, uint32_t served, uint64_t scan_ticks)
+{
+    __hip_atomic_store(exit_word + 1, served, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(exit_word + 2, (uint32_t)scan_ticks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(exit_word + 3, (uint32_t)(scan_ticks >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(exit_word, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Mailbox: 64 lines of 64 bytes; dword 15 of EVERY line repeats seq, so a torn read of any line is detected and retried.
+//   line 0      [0] seq [1] cmd (0 scan, 1 quit) [2] next_arc [3] rstar [4] n_pi [5] n_st [6..9] two {arc, state} [10..12] patch 0 {node, lo, hi}
+//   line 1..63  five patches {node, value lo, value hi} each (patches 1..n_pi-1)
+// The poll reads line 0 only (one 64-byte read per workgroup per poll); the other lines are fetched when n_pi > 1.
+template <typename T, int RULE, bool OPT, bool REG>
+__global__ __launch_bounds__(kResidentThreads) void resident_kernel(const ResidentParams<T> p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lm[kMailboxLines * 16];
+    __shared__ uint32_t s_timeout;
+    const int tid = threadIdx.x;
+    const int my_i0 = blockIdx.x * kResidentTile + tid * kArcsPerThread;
+    TileData<T> mine;
+    if (REG) load_tile<T>(p.src, p.tgt, p.cost, p.state, my_i0, mine);
+    uint32_t last = p.start_seq, served = 0;
+    uint64_t scan_ticks = 0;
+    uint64_t idle_since = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        // ---- wait for a request
+        if (tid < 4) mailbox_load16(p.mailbox + tid * 4, lm + tid * 4);
+        if (tid == 0) s_timeout = (__builtin_amdgcn_s_memrealtime() - idle_since > p.idle_ticks) ? 1u : 0u;
+        __syncthreads();
+        const uint32_t seq = lm[0];
+        int n_pi = (int)lm[4];
+        n_pi = n_pi < 0 ? 0 : (n_pi > p.max_pi ? p.max_pi : n_pi);
+        const int lines = n_pi <= 1 ? 1 : 1 + (n_pi - 1 + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
+        const bool ok = seq != last && lm[15] == seq;
+        const bool timed_out = s_timeout != 0;
+        const uint32_t cmd = lm[1];
+        const int next_arc = (int)lm[2], rstar = (int)lm[3];
+        int n_st = (int)lm[5];
+        n_st = n_st < 0 ? 0 : (n_st > kResidentMaxState ? kResidentMaxState : n_st);
+        const int st_arc0 = (int)lm[6], st_arc1 = (int)lm[8];
+        const uint32_t st_val0 = lm[7], st_val1 = lm[9];
+        const uint32_t p0_node = lm[10], p0_lo = lm[11], p0_hi = lm[12];
+        __syncthreads();                                   // everybody has read line 0 before anybody overwrites lm
+        if (!ok) {
+            if (timed_out) {
+                if (tid == 0 && blockIdx.x == 0) resident_exit(p.exit_word, 2u, served, scan_ticks);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        const uint64_t t_seen = __builtin_amdgcn_s_memrealtime();
+        if (cmd != 0) {                                    // quit
+            if (tid == 0 && blockIdx.x == 0) resident_exit(p.exit_word, 1u, served, scan_ticks);
+            return;
+        }
+        // ---- patches: final values, applied by EVERY workgroup before it reads (same argument as scan_kernel).
+        // Patch 0 rides in the header; the rest comes in chunks of 1023 lines (one is enough for 5115 patches), each line verified by its tag.
+        bool torn = false;
+        for (int first = 1; first < lines; first += kChunkLines) {
+            const int chunk = lines - first < kChunkLines ? lines - first : kChunkLines;
+            {   // all of a thread's (up to four) 16-byte reads are in flight together; one wait, then LDS
+                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                v4u x[kMailboxLines * 4 / kResidentThreads];
 #pragma unroll
-        for (int w = 1; w < kThreads / 64; ++w) take_if_better<RULE>(k, wave_best[w].c, wave_best[w].r, wave_best[w].p);
-        uint4 out;
-        out.x = (uint32_t)(uint64_t)k.c;
-        out.y = (uint32_t)((uint64_t)k.c >> 32);
-        out.z = k.p;
-        out.w = p.seq;
-        *reinterpret_cast<uint4 *>(p.slots + blockIdx.x) = out;
+                for (int k = 0; k < kMailboxLines * 4 / kResidentThreads; ++k) {
+                    x[k] = v4u{0u, 0u, 0u, 0u};
+                    const int c = tid + k * kResidentThreads;
+                    if (c < chunk * 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x[k]) : "v"(p.mailbox + ((size_t)first * 16 + c * 4)) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])::"memory");
+#pragma unroll
+                for (int k = 0; k < kMailboxLines * 4 / kResidentThreads; ++k) {
+                    const int c = tid + k * kResidentThreads;
+                    if (c < chunk * 4) *reinterpret_cast<v4u *>(lm + 16 + c * 4) = x[k];
+                }
+            }
+            __syncthreads();
+            int bad = 0;
+            for (int l = tid; l < chunk; l += kResidentThreads) bad |= (lm[(1 + l) * 16 + 15] != seq);
+            if (__syncthreads_or(bad)) { torn = true; break; }
+            const int i_lo = 1 + (first - 1) * kMailboxPatchesPerLine;
+            const int i_hi = n_pi < i_lo + chunk * kMailboxPatchesPerLine ? n_pi : i_lo + chunk * kMailboxPatchesPerLine;
+            for (int i = i_lo + tid; i < i_hi; i += kResidentThreads) {
+                const int rel = i - i_lo;
+                const uint32_t *q = lm + (1 + rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
+                const int64_t v = (int64_t)(((uint64_t)q[2] << 32) | q[1]);
+                p.pi[q[0]] = (T)v;
+            }
+            __syncthreads();                               // the chunk has been consumed before the next one lands in lm
+        }
+        if (torn) continue;                                // a line was still in flight: poll again (re-applying final values is harmless)
+        if (n_pi | n_st) {
+            if (tid == 0 && n_pi > 0) p.pi[p0_node] = (T)(int64_t)(((uint64_t)p0_hi << 32) | p0_lo);
+            if (tid == 64 && n_st > 0) { const int a = st_arc0 - p.base; if ((unsigned)a < (unsigned)p.count_padded) p.state[a] = (int8_t)st_val0; }
+            if (tid == 65 && n_st > 1) { const int a = st_arc1 - p.base; if ((unsigned)a < (unsigned)p.count_padded) p.state[a] = (int8_t)st_val1; }
+            if (REG) {
+                if (n_st > 0) { const int a = st_arc0 - p.base - my_i0; if ((unsigned)a < 4u) mine.st4 = (mine.st4 & ~(0xFFu << (8 * a))) | ((st_val0 & 0xFFu) << (8 * a)); }
+                if (n_st > 1) { const int a = st_arc1 - p.base - my_i0; if ((unsigned)a < 4u) mine.st4 = (mine.st4 & ~(0xFFu << (8 * a))) | ((st_val1 & 0xFFu) << (8 * a)); }
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+        }
+        // ---- scan
+        Key best;
+        best.c = 0;
+        best.r = kNone;
+        best.p = kNone;
+        if (REG) {
+            eval_tile<T, RULE, OPT>(mine, p.pi, p.base + my_i0, p.m_s, next_arc, p.block_size, rstar, best);
+        } else {
+            for (int i0 = my_i0; i0 < p.count_padded; i0 += gridDim.x * kResidentTile) {
+                TileData<T> d;
+                load_tile<T>(p.src, p.tgt, p.cost, p.state, i0, d);
+                eval_tile<T, RULE, OPT>(d, p.pi, p.base + i0, p.m_s, next_arc, p.block_size, rstar, best);
+            }
+        }
+        publish_best<RULE, true, kResidentThreads>(best, p.slots + blockIdx.x, seq);
+        last = seq;
+        served += 1;
+        idle_since = __builtin_amdgcn_s_memrealtime();
+        scan_ticks += idle_since - t_seen;
+        __syncthreads();                                   // lm and wave_best are reused by the next request
     }
 }
 
@@ -281,6 +478,7 @@ struct mcf_engine {
     bool uploaded = false;
     // host mirror of pi: patches carry final values
     std::vector<int64_t> pi;
+    bool mirror_valid = false;     // mcf_engine_set_potential stops maintaining the mirror; update_potential rebuilds it on demand
     int64_t max_abs_cost = 0;
     // pending patches of the current pivot
     std::vector<int32_t> pend_node, pend_arc, pend_state;
@@ -304,6 +502,13 @@ struct mcf_engine {
     void *comm = nullptr;
     int rank = 0, world = 1;
     mcf_candidate *d_cand_local = nullptr, *d_cand_all = nullptr, *h_cand_all = nullptr;
+    // resident mode (flag MCF_ENGINE_RESIDENT): mailbox in BAR-mapped fine-grained VRAM, exit record in pinned host memory
+    bool resident_ok = false, resident_running = false, resident_reg = false;
+    uint32_t *mailbox = nullptr;
+    int mailbox_lines = 0;
+    uint32_t *h_exit = nullptr, *d_exit = nullptr;
+    int res_grid = 0;
+    hipEvent_t res_start = nullptr, res_stop = nullptr;
     // flush buffer for cold micro-benchmarks
     void *d_flush = nullptr;
     size_t flush_bytes = 0;
@@ -430,8 +635,173 @@ int flush_pending(mcf_engine *e)
     return MCF_OK;
 }
 
+// ---- fine-grained VRAM that the CPU can write through the PCIe BAR (what HIP itself uses for device-side kernel arguments)
+struct HsaPick {
+    int want_bdf = -1, want_domain = -1, ordinal = 0, seen = 0;
+    hsa_agent_t cpu{}, gpu{};
+    bool have_cpu = false, have_gpu = false, have_pool = false;
+    hsa_amd_memory_pool_t pool{};
+};
+hsa_status_t hsa_pool_cb(hsa_amd_memory_pool_t pool, void *data)
+{
+    HsaPick *k = (HsaPick *)data;
+    hsa_amd_segment_t seg;
+    if (hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg) != HSA_STATUS_SUCCESS || seg != HSA_AMD_SEGMENT_GLOBAL) return HSA_STATUS_SUCCESS;
+    uint32_t flags = 0;
+    bool alloc = false;
+    hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+    hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+    if (alloc && (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_FINE_GRAINED) && !k->have_pool) { k->pool = pool; k->have_pool = true; }
+    return HSA_STATUS_SUCCESS;
+}
+hsa_status_t hsa_agent_cb(hsa_agent_t a, void *data)
+{
+    HsaPick *k = (HsaPick *)data;
+    hsa_device_type_t t;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if (t == HSA_DEVICE_TYPE_CPU && !k->have_cpu) { k->cpu = a; k->have_cpu = true; }
+    if (t == HSA_DEVICE_TYPE_GPU) {
+        uint32_t bdf = 0, domain = 0;
+        hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
+        hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
+        const bool by_bdf = k->want_bdf >= 0 && (int)(bdf >> 8) == k->want_bdf && (k->want_domain < 0 || (int)domain == k->want_domain);
+        const bool by_ord = k->want_bdf < 0 && k->seen == k->ordinal;
+        if (!k->have_gpu && (by_bdf || by_ord)) { k->gpu = a; k->have_gpu = true; hsa_amd_agent_iterate_memory_pools(a, hsa_pool_cb, k); }
+        k->seen++;
+    }
+    return HSA_STATUS_SUCCESS;
+}
+// returns nullptr when the platform offers no host-writable fine-grained VRAM (resident mode is then simply not used)
+uint32_t *alloc_bar_vram(int hip_device, size_t bytes)
+{
+    if (hsa_init() != HSA_STATUS_SUCCESS) return nullptr;
+    HsaPick k;
+    int bus = -1, dom = -1;
+    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, hip_device) == hipSuccess) k.want_bdf = bus;
+    if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, hip_device) == hipSuccess) k.want_domain = dom;
+    k.ordinal = hip_device;
+    hsa_iterate_agents(hsa_agent_cb, &k);
+    if (!k.have_gpu) { k = HsaPick{}; k.ordinal = hip_device; hsa_iterate_agents(hsa_agent_cb, &k); }
+    if (!k.have_gpu || !k.have_cpu || !k.have_pool) return nullptr;
+    void *ptr = nullptr;
+    if (hsa_amd_memory_pool_allocate(k.pool, bytes, 0, &ptr) != HSA_STATUS_SUCCESS) return nullptr;
+    hsa_agent_t both[2] = {k.cpu, k.gpu};
+    if (hsa_amd_agents_allow_access(2, both, nullptr, ptr) != HSA_STATUS_SUCCESS) { hsa_amd_memory_pool_free(ptr); return nullptr; }
+    return (uint32_t *)ptr;
+}
+
+constexpr int kResidentMaxGrid = 256;       // one 1024-thread workgroup per CU: always co-resident
+constexpr uint32_t kResidentIdleTicks = 25000000u;   // 0.25 s of s_memrealtime
+
+template <typename T, int RULE, bool OPT>
+void launch_resident_r(mcf_engine *e, const ResidentParams<T> &p)
+{
+    const dim3 grid(e->res_grid), block(kResidentThreads);
+    if (e->resident_reg) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    else hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+}
+
+template <typename T>
+int launch_resident(mcf_engine *e, uint32_t start_seq)
+{
+    ResidentParams<T> p;
+    p.src = e->d_src; p.tgt = e->d_tgt; p.cost = (const T *)e->d_cost; p.state = e->d_state; p.pi = (T *)e->d_pi;
+    p.slots = e->d_slots; p.mailbox = e->mailbox; p.exit_word = e->d_exit;
+    p.base = e->begin; p.count_padded = e->count_padded; p.m_s = e->d.search_arc_num; p.block_size = e->block_size;
+    p.start_seq = start_seq; p.idle_ticks = kResidentIdleTicks; p.max_pi = e->d.node_count;
+    const bool opt = e->d.semantics == MCF_SEM_OPTIMIZED;
+    switch (e->d.rule) {
+    case MCF_RULE_BEST_ELIGIBLE: launch_resident_r<T, MCF_RULE_BEST_ELIGIBLE, false>(e, p); break;
+    case MCF_RULE_FIRST_ELIGIBLE: launch_resident_r<T, MCF_RULE_FIRST_ELIGIBLE, false>(e, p); break;
+    default:
+        if (opt) launch_resident_r<T, MCF_RULE_BLOCK_SEARCH, true>(e, p);
+        else launch_resident_r<T, MCF_RULE_BLOCK_SEARCH, false>(e, p);
+    }
+    HIP_TRY(hipGetLastError());
+    return MCF_OK;
+}
+
+int resident_start(mcf_engine *e, uint32_t start_seq)
+{
+    if (e->resident_running) return MCF_OK;
+    for (int i = 0; i < 4; ++i) ((volatile uint32_t *)e->h_exit)[i] = 0;
+    int rc = e->d.int_width == 32 ? launch_resident<int32_t>(e, start_seq) : launch_resident<int64_t>(e, start_seq);
+    if (rc) return rc;
+    e->resident_running = true;
+    e->st.resident_launches += 1;
+    return MCF_OK;
+}
+
+// one 64-byte line into the write-combining BAR mapping: four 16-byte stores, the tag goes out with the last one
+inline void mailbox_write_line(uint32_t *dst, const uint32_t *line16)
+{
+    const __m128i *src = (const __m128i *)line16;
+    __m128i *d = (__m128i *)dst;
+    _mm_store_si128(d + 0, _mm_loadu_si128(src + 0));
+    _mm_store_si128(d + 1, _mm_loadu_si128(src + 1));
+    _mm_store_si128(d + 2, _mm_loadu_si128(src + 2));
+    _mm_store_si128(d + 3, _mm_loadu_si128(src + 3));
+}
+
+void resident_post(mcf_engine *e, uint32_t seq, uint32_t cmd, bool with_patches)
+{
+    alignas(16) uint32_t line[16];
+    const int n_pi = with_patches ? (int)e->pend_node.size() : 0, n_st = with_patches ? (int)e->pend_arc.size() : 0;
+    for (int l = 0, i = 1; i < n_pi; ++l) {                 // patches 1.. go to lines 1..; patch 0 rides in the header
+        memset(line, 0, sizeof(line));
+        for (int k = 0; k < kMailboxPatchesPerLine && i < n_pi; ++k, ++i) {
+            const uint64_t v = (uint64_t)e->pend_val[i];
+            line[3 * k] = (uint32_t)e->pend_node[i];
+            line[3 * k + 1] = (uint32_t)v;
+            line[3 * k + 2] = (uint32_t)(v >> 32);
+        }
+        line[15] = seq;
+        mailbox_write_line(e->mailbox + 16 * (size_t)(l + 1), line);
+    }
+    memset(line, 0, sizeof(line));
+    line[0] = seq;
+    line[1] = cmd;
+    const int na = e->next_arc >= e->d.search_arc_num ? 0 : e->next_arc;
+    line[2] = (uint32_t)na;
+    int rstar = -1;
+    if (e->d.rule == MCF_RULE_BLOCK_SEARCH && e->d.semantics == MCF_SEM_OPTIMIZED && e->next_arc < e->d.search_arc_num) {
+        const int len1 = e->d.search_arc_num - e->next_arc;
+        if (len1 % e->block_size != 0) rstar = len1 / e->block_size;
+    }
+    line[3] = (uint32_t)rstar;
+    line[4] = (uint32_t)n_pi;
+    line[5] = (uint32_t)n_st;
+    for (int k = 0; k < n_st; ++k) { line[6 + 2 * k] = (uint32_t)e->pend_arc[k]; line[7 + 2 * k] = (uint32_t)e->pend_state[k]; }
+    if (n_pi > 0) {
+        const uint64_t v = (uint64_t)e->pend_val[0];
+        line[10] = (uint32_t)e->pend_node[0];
+        line[11] = (uint32_t)v;
+        line[12] = (uint32_t)(v >> 32);
+    }
+    line[15] = seq;
+    if (n_pi > 1) _mm_sfence();                     // patch lines leave the write-combining buffers before the header does
+    mailbox_write_line(e->mailbox, line);
+    _mm_sfence();
+}
+
+int resident_stop(mcf_engine *e)
+{
+    if (!e->resident_running) return MCF_OK;
+    e->seq += 1;
+    if (e->seq == 0) e->seq = 1;
+    resident_post(e, e->seq, 1u, false);
+    HIP_TRY(hipStreamSynchronize(e->stream));       // bounded: the grid leaves on quit, or by itself after kResidentIdleTicks
+    e->resident_running = false;
+    const volatile uint32_t *x = e->h_exit;
+    e->st.resident_requests += x[1];
+    e->st.resident_scan_ns += 10.0 * (double)(((uint64_t)x[3] << 32) | x[2]);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->res_start, e->res_stop) == hipSuccess) e->st.resident_kernel_ns += (double)ms * 1e6;
+    return MCF_OK;
+}
+
 // wait for the `grid` records of dispatch `seq`, merge them with the rule's ordering
-int collect(mcf_engine *e, Key *out)
+int collect(mcf_engine *e, int grid, Key *out)
 {
     const double t0 = mcf::now_ns();
     const bool block_rule = e->d.rule == MCF_RULE_BLOCK_SEARCH, best_rule = e->d.rule == MCF_RULE_BEST_ELIGIBLE;
@@ -444,14 +814,22 @@ int collect(mcf_engine *e, Key *out)
         return len1 % e->block_size ? len1 / e->block_size : -1;
     }();
     const int na = e->next_arc >= e->d.search_arc_num ? 0 : e->next_arc;
-    for (int g = 0; g < e->grid; ++g) {
+    for (int g = 0; g < grid; ++g) {
         uint64_t spins = 0;
         while (slots[g].tag != seq) {
             _mm_pause();
+            if (e->resident_running && (spins & 0xFFF) == 0xFFF && ((const volatile uint32_t *)e->h_exit)[0] != 0) {
+                // the resident grid left on its idle timeout while this request was on its way: start it again, it will
+                // find the request in the mailbox (start_seq = the previous request)
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                e->resident_running = false;
+                int rc = resident_start(e, seq - 1 == 0 ? 0xFFFFFFFFu : seq - 1);
+                if (rc) return rc;
+            }
             if ((++spins & 0xFFFFF) == 0) {
                 const hipError_t q = hipStreamQuery(e->stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return mcf::fail(MCF_ERR_HIP, "scan dispatch failed: %s", hipGetErrorString(q));
-                if (mcf::now_ns() - t0 > 20e9) return mcf::fail(MCF_ERR_TIMEOUT, "no answer from the device after 20 s (workgroup %d of %d)", g, e->grid);
+                if (mcf::now_ns() - t0 > 20e9) return mcf::fail(MCF_ERR_TIMEOUT, "no answer from the device after 20 s (workgroup %d of %d)", g, grid);
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
@@ -480,11 +858,35 @@ int local_search(mcf_engine *e, Key *k)
 {
     if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
     const double t0 = mcf::now_ns();
+    const bool had = !e->pend_node.empty() || !e->pend_arc.empty();
+    if (e->resident_ok) {
+        // ---- resident mode: post the request into the mailbox, the grid is already running
+        const bool fits = (int)e->pend_arc.size() <= kResidentMaxState;     // any number of potentials fits the mailbox
+        if (!fits) {
+            // a list that does not fit the mailbox: stop the grid, ship it with update_kernel, start again
+            int rc = resident_stop(e);
+            if (!rc) rc = flush_pending(e);
+            if (rc) return rc;
+        }
+        const uint32_t prev = e->seq;
+        e->seq += 1;
+        if (e->seq == 0) e->seq = 1;
+        int rc = resident_start(e, prev);
+        if (rc) return rc;
+        resident_post(e, e->seq, 0u, fits);
+        if (fits) {
+            if (had) e->st.inline_updates += 1;
+            e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
+        }
+        e->st.host_launch_ns += mcf::now_ns() - t0;
+        e->st.searches += 1;
+        e->st.arcs_scanned += e->end - e->begin;
+        return collect(e, e->res_grid, k);
+    }
     e->seq += 1;
     if (e->seq == 0) e->seq = 1;
     const bool inline_ok = !(e->d.flags & MCF_ENGINE_NO_INLINE_UPDATE) && (int)e->pend_node.size() <= kInlinePi &&
                            (int)e->pend_arc.size() <= kInlineState;
-    const bool had = !e->pend_node.empty() || !e->pend_arc.empty();
     if (!inline_ok) { int rc = flush_pending(e); if (rc) return rc; }
     const bool timed = (e->d.flags & MCF_ENGINE_TIME_EVERY_KERNEL) ||
                        ((e->d.flags & MCF_ENGINE_SAMPLE_KERNEL_TIME) && (e->st.scan_launches & 15) == 0);
@@ -496,7 +898,7 @@ int local_search(mcf_engine *e, Key *k)
     }
     e->st.host_launch_ns += mcf::now_ns() - t0;
     e->st.searches += 1;
-    rc = collect(e, k);
+    rc = collect(e, e->grid, k);
     if (rc) return rc;
     if (timed) drain_events(e, false);
     return MCF_OK;
@@ -644,8 +1046,32 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         mcf_engine_destroy(e);
         return rc;
     }
-    e->st.scan_workgroups = e->grid;
-    e->st.scan_threads = kThreads;
+    // resident mode: wanted by flag or MCF_HIP_RESIDENT=1, never for sharded engines (the RCCL exchange needs the stream)
+    {
+        const char *env = getenv("MCF_HIP_RESIDENT");
+        bool want = (desc->flags & MCF_ENGINE_DISPATCH) == 0;      // resident unless dispatch mode is asked for
+        if (env && env[0] == '1') want = true;
+        if (env && env[0] == '0') want = false;
+        const bool whole = e->begin == 0 && e->end == desc->search_arc_num;
+        if (want && whole && !(desc->flags & (MCF_ENGINE_TIME_EVERY_KERNEL | MCF_ENGINE_NO_INLINE_UPDATE))) {
+            e->mailbox_lines = 2 + (desc->node_count + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
+            e->mailbox = alloc_bar_vram(desc->device, (size_t)e->mailbox_lines * 64);
+            if (e->mailbox && hipHostMalloc((void **)&e->h_exit, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+                hipHostGetDevicePointer((void **)&e->d_exit, e->h_exit, 0) == hipSuccess &&
+                hipEventCreate(&e->res_start) == hipSuccess && hipEventCreate(&e->res_stop) == hipSuccess) {
+                alignas(16) uint32_t zero[16] = {0};
+                for (int l = 0; l < e->mailbox_lines; ++l) mailbox_write_line(e->mailbox + 16 * (size_t)l, zero);
+                _mm_sfence();
+                const int tiles = e->count_padded / kResidentTile;
+                e->resident_reg = tiles <= kResidentMaxGrid;
+                e->res_grid = e->resident_reg ? tiles : kResidentMaxGrid;
+                e->resident_ok = true;
+            }
+        }
+    }
+    e->st.scan_workgroups = e->resident_ok ? e->res_grid : e->grid;
+    e->st.scan_threads = e->resident_ok ? kResidentThreads : kThreads;
+    e->st.resident = e->resident_ok ? 1 : 0;
     e->st.bytes_per_scan = (int64_t)(desc->int_width == 64 ? 17 : 13) * count + (int64_t)w * desc->node_count;
     *out = e;
     return MCF_OK;
@@ -655,7 +1081,12 @@ void mcf_engine_destroy(mcf_engine *e)
 {
     if (!e) return;
     (void)hipSetDevice(e->d.device);
+    if (e->resident_running) (void)resident_stop(e);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->mailbox) hsa_amd_memory_pool_free(e->mailbox);
+    if (e->h_exit) (void)hipHostFree(e->h_exit);
+    if (e->res_start) (void)hipEventDestroy(e->res_start);
+    if (e->res_stop) (void)hipEventDestroy(e->res_stop);
     if (e->comm && rccl() && rccl()->comm_destroy) rccl()->comm_destroy(e->comm);
     (void)hipFree(e->d_src); (void)hipFree(e->d_tgt); (void)hipFree(e->d_cost); (void)hipFree(e->d_state); (void)hipFree(e->d_pi);
     (void)hipFree(e->d_cand_local); (void)hipFree(e->d_cand_all); (void)hipFree(e->d_flush);
@@ -680,6 +1111,7 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
 {
     if (!e || !source || !target || !cost || !state || !pi) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_upload: null argument");
     HIP_TRY(hipSetDevice(e->d.device));
+    if (int rcs = resident_stop(e)) return rcs;
     const int n = e->d.node_count, count = e->end - e->begin, cp = e->count_padded;
     for (int i = e->begin; i < e->end; ++i)
         if ((unsigned)source[i] >= (unsigned)n || (unsigned)target[i] >= (unsigned)n)
@@ -716,6 +1148,7 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
         HIP_TRY(hipMemcpy(e->d_pi, pi, sizeof(int64_t) * n, hipMemcpyHostToDevice));
     }
     e->pi.assign(pi, pi + n);
+    e->mirror_valid = true;
     e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
     e->next_arc = 0;
     e->uploaded = true;
@@ -745,8 +1178,13 @@ int mcf_engine_update_potential(mcf_engine *e, int32_t count, const int32_t *nod
     if (!e || count < 0 || (count && !nodes)) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_update_potential: bad arguments");
     if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
     if (count == 0) return MCF_OK;
+    if (!e->mirror_valid) {          // the caller switched from set_potential to += sigma: fetch the current values once
+        int rc = mcf_engine_download_pi(e, e->pi.data());
+        if (rc) return rc;
+        e->mirror_valid = true;
+    }
     // one list per dispatch: a second list may repeat nodes of the first
-    if (!e->pend_node.empty()) { int rc = flush_pending(e); if (rc) return rc; }
+    if (!e->pend_node.empty()) { int rc = resident_stop(e); if (!rc) rc = flush_pending(e); if (rc) return rc; }
     if (count > e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "%d nodes in a graph of %d", count, e->d.node_count);
     e->pend_node.resize(count);
     e->pend_val.resize(count);
@@ -763,11 +1201,31 @@ int mcf_engine_update_potential(mcf_engine *e, int32_t count, const int32_t *nod
     return MCF_OK;
 }
 
+int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values)
+{
+    if (!e || count < 0 || (count && (!nodes || !values))) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_set_potential: bad arguments");
+    if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
+    if (count == 0) return MCF_OK;
+    if (!e->pend_node.empty()) { int rc = resident_stop(e); if (!rc) rc = flush_pending(e); if (rc) return rc; }
+    if (count > e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "%d nodes in a graph of %d", count, e->d.node_count);
+    const bool narrow = e->d.int_width == 32;
+    for (int i = 0; i < count; ++i) {
+        if ((unsigned)nodes[i] >= (unsigned)e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "node %d out of range", nodes[i]);
+        if (narrow && !fits32(values[i])) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d leaves int32; create the engine with int_width 64", nodes[i]);
+    }
+    e->pend_node.assign(nodes, nodes + count);
+    e->pend_val.assign(values, values + count);
+    e->mirror_valid = false;
+    e->st.potential_nodes += count;
+    return MCF_OK;
+}
+
 int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, const int32_t *source, const int32_t *target, const int64_t *cost)
 {
     if (!e || count < 0 || (count && (!arcs || !source || !target || !cost))) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_patch_arcs: bad arguments");
     HIP_TRY(hipSetDevice(e->d.device));
-    int rc = flush_pending(e);
+    int rc = resident_stop(e);
+    if (!rc) rc = flush_pending(e);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     for (int i = 0; i < count; ++i) {
@@ -836,6 +1294,13 @@ int mcf_resolve_candidates(int32_t rule, int32_t semantics, int32_t search_arc_n
     return MCF_OK;
 }
 
+int mcf_engine_park(mcf_engine *e)
+{
+    if (!e) return mcf::fail(MCF_ERR_INVALID, "null argument");
+    (void)hipSetDevice(e->d.device);
+    return resident_stop(e);
+}
+
 int mcf_engine_get_next_arc(mcf_engine *e, int32_t *next_arc) { if (!e || !next_arc) return mcf::fail(MCF_ERR_INVALID, "null argument"); *next_arc = e->next_arc; return MCF_OK; }
 int mcf_engine_set_next_arc(mcf_engine *e, int32_t next_arc)
 {
@@ -849,7 +1314,8 @@ int mcf_engine_download_pi(mcf_engine *e, int64_t *out)
 {
     if (!e || !out) return mcf::fail(MCF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(e->d.device));
-    int rc = flush_pending(e);
+    int rc = resident_stop(e);
+    if (!rc) rc = flush_pending(e);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     const int n = e->d.node_count;
@@ -867,7 +1333,8 @@ int mcf_engine_download_state(mcf_engine *e, int8_t *out)
 {
     if (!e || !out) return mcf::fail(MCF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(e->d.device));
-    int rc = flush_pending(e);
+    int rc = resident_stop(e);
+    if (!rc) rc = flush_pending(e);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(out + e->begin, e->d_state, e->end - e->begin, hipMemcpyDeviceToHost));
@@ -878,7 +1345,8 @@ int mcf_engine_get_stats(mcf_engine *e, mcf_engine_stats *out)
 {
     if (!e || !out) return mcf::fail(MCF_ERR_INVALID, "null argument");
     (void)hipSetDevice(e->d.device);
-    int rc = drain_events(e, true);
+    int rc = resident_stop(e);
+    if (!rc) rc = drain_events(e, true);
     if (rc) return rc;
     *out = e->st;
     return MCF_OK;
@@ -894,6 +1362,7 @@ int mcf_engine_reset_stats(mcf_engine *e)
     e->st.scan_workgroups = keep.scan_workgroups;
     e->st.scan_threads = keep.scan_threads;
     e->st.bytes_per_scan = keep.bytes_per_scan;
+    e->st.resident = keep.resident;
     return MCF_OK;
 }
 
@@ -902,7 +1371,8 @@ int mcf_engine_bench_scan(mcf_engine *e, int32_t reps, int32_t cold, int64_t flu
     if (!e || reps < 1 || !avg_ns || !min_ns) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_bench_scan: bad arguments");
     if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
     HIP_TRY(hipSetDevice(e->d.device));
-    int rc = flush_pending(e);
+    int rc = resident_stop(e);
+    if (!rc) rc = flush_pending(e);
     if (rc) return rc;
     if (cold) {
         const size_t want = (size_t)std::max<int64_t>(flush_bytes, 1 << 20);

@@ -47,6 +47,7 @@ struct mcf_ns {
     int32_t st_arc[2] = {0, 0};
     int8_t st_val[2] = {0, 0};
     std::vector<int32_t> moved;
+    std::vector<int64_t> moved_val;   // their new potentials
     int64_t sigma = 0;
     // engine + sharding
     mcf_engine *engine = nullptr;
@@ -270,8 +271,9 @@ void shift_potentials(mcf_ns *s)
     s->sigma = s->pi[s->v_in] - s->pi[s->u_in] - s->par_dir[s->u_in] * s->cost[s->in_arc];
     const int stop = s->nxt[s->fin[s->u_in]];
     for (int u = s->u_in; u != stop; u = s->nxt[u]) {
-        s->pi[u] += s->sigma;
+        const int64_t v = (s->pi[u] += s->sigma);
         s->moved.push_back(u);
+        s->moved_val.push_back(v);
     }
 }
 
@@ -280,6 +282,7 @@ bool pivot(mcf_ns *s, int arc, double *t_tree, double *t_pot)
 {
     s->in_arc = arc;
     s->moved.clear();
+    s->moved_val.clear();
     s->sigma = 0;
     find_join(s);
     const bool change = find_leaving(s);
@@ -561,11 +564,12 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         if (pivot(s, arc, &t_tree, &t_pot)) { s->status = MCF_UNBOUNDED; break; }
         const double t1 = mcf::now_ns();
         rc = mcf_engine_patch_state(s->engine, s->n_state, s->st_arc, s->st_val);
-        if (!rc && !s->moved.empty()) rc = mcf_engine_update_potential(s->engine, (int32_t)s->moved.size(), s->moved.data(), s->sigma);
+        if (!rc && !s->moved.empty()) rc = mcf_engine_set_potential(s->engine, (int32_t)s->moved.size(), s->moved.data(), s->moved_val.data());
         t_pot += mcf::now_ns() - t1;
         if (rc) return rc;
         s->metrics.potential_nodes += (int64_t)s->moved.size();
     }
+    mcf_engine_park(s->engine);      // a resident scan grid must not outlive Solve()
     s->trace_len = std::min(it, s->trace_cap);
     s->metrics.iterations = it;
     if (s->status == MCF_NOT_SOLVED) finish(s);

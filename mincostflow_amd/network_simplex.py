@@ -246,6 +246,10 @@ class PivotEngine:
         nodes = _i32(nodes)
         L.check(L.lib().mcf_engine_update_potential(self._h, len(nodes), nodes, sigma))
 
+    def set_potential(self, nodes, values):
+        nodes, values = _i32(nodes), _i64(values)
+        L.check(L.lib().mcf_engine_set_potential(self._h, len(nodes), nodes, values))
+
     def patch_arcs(self, arcs, source, target, cost):
         arcs = _i32(arcs)
         L.check(L.lib().mcf_engine_patch_arcs(self._h, len(arcs), arcs, _i32(source), _i32(target), _i64(cost)))
@@ -286,6 +290,9 @@ class PivotEngine:
 
     def stats(self) -> dict:
         s = L.EngineStats(); L.check(L.lib().mcf_engine_get_stats(self._h, C.byref(s))); return s.as_dict()
+
+    def park(self):
+        L.check(L.lib().mcf_engine_park(self._h))
 
     def reset_stats(self):
         L.check(L.lib().mcf_engine_reset_stats(self._h))
