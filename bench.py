@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline sample")
     ap.add_argument("--sharded-pivots", type=int, default=0, help="N>1: also time this many pivots of config 5 sharded over RCCL")
     ap.add_argument("--dispatch", action="store_true", help="one scan dispatch per search instead of the resident grid")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo: rehearsals on one GPU)")
     return ap.parse_args()
 
 
@@ -114,16 +115,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
+    import mincostflow_amd as M
+    if M.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: libmcf_hip.so has no CPU path")
+    dev = local_rank % M.device_count()          # one rank per GPU; ranks only share a GPU in gloo rehearsals
     dist = None
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))     # nccl == RCCL on ROCm
-
-    import mincostflow_amd as M
-    if M.device_count() <= local_rank:
-        raise SystemExit("bench.py needs an MI355X: libmcf_hip.so has no CPU path")
-    torch.cuda.set_device(local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))     # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+    local_rank = dev
 
     g, rule, width, desc = workload(args.workload, SEED + rank)
 
@@ -150,7 +155,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_max = float(t.item())
     else:
@@ -161,11 +166,32 @@ def main():
     cost = solvers[0].get_total_cost()
     pivots = sum(m["iterations"] for m in mets)
     if dist is not None:
-        t = torch.tensor([pivots], dtype=torch.int64, device="cuda")
+        t = torch.tensor([pivots], dtype=torch.int64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         pivots_all = int(t.item())
     else:
         pivots_all = pivots
+
+    sharded = None
+    if dist is not None and args.sharded_pivots > 0 and args.backend == "nccl":
+        # BASELINE.json configs[4]: ONE instance, arcs sharded over the ranks, RCCL all-gather MINLOC per pivot
+        g5 = M.netgen_like(SEED, 1_000_000, 8_000_000, 1000, 1000)
+        ident = torch.from_numpy(M.comm_unique_id() if rank == 0 else __import__("numpy").zeros(128, "uint8")).cuda()
+        dist.broadcast(ident, src=0)
+        ns5 = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True)
+        ns5.set_device(dev, 64, 0, 0).set_sharding(ident.cpu().numpy(), rank, world).set_pivot_limit(args.sharded_pivots).prepare()
+        barrier()
+        ts = time.perf_counter()
+        ns5.solve()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        m5 = ns5.get_metrics()
+        sharded = {"workload": "NETGEN-like 1M nodes / 8M arcs, Best Eligible, int64, arcs sharded over the ranks",
+                   "exchange": "ncclAllGather of 16 B per rank + local MINLOC, every pivot", "ranks": world, "pivots": m5["iterations"],
+                   "seconds": float(t.item()), "us_per_pivot": float(t.item()) / max(m5["iterations"], 1) * 1e6,
+                   "pivots_per_s": m5["iterations"] / float(t.item())}
+        del ns5, g5
 
     if rank != 0:
         if dist is not None:
@@ -240,6 +266,8 @@ def main():
                           "note": "7.6 MB per scan lives in L2 / Infinity Cache and the per-pivot cost is host <-> device latency, not bandwidth; "
                                   "scan_microbench holds the bandwidth-bound sizes"}, **extra),
     }
+    if sharded is not None:
+        line["sharded"] = sharded
     if not args.no_cpu_baseline and args.gpus == 1:
         line["cpu_baseline"] = cpu_baseline(g, rule, args.cpu_seconds)
         if rule != M.PivotRule.BlockSearch:

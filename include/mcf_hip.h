@@ -242,6 +242,8 @@ typedef struct mcf_ns_metrics {
     mcf_engine_stats engine;
 } mcf_ns_metrics;
 MCF_API int mcf_ns_get_metrics(mcf_ns *s, mcf_ns_metrics *out);                            /* NS.cs:584-587 */
+/* measurement aid: Solve() stops after max_pivots pivots and reports MCF_NOT_SOLVED (0 = no limit) */
+MCF_API int mcf_ns_set_pivot_limit(mcf_ns *s, int64_t max_pivots);
 /* optional pivot trace: entering arc of every pivot of the next Solve() (for parity tests) */
 MCF_API int mcf_ns_set_trace(mcf_ns *s, int32_t *trace, int64_t capacity);
 MCF_API int mcf_ns_get_trace_length(mcf_ns *s, int64_t *length);

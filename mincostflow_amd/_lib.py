@@ -127,6 +127,7 @@ SIGNATURES = {
     "mcf_ns_get_potentials": (C.c_int, [C.c_void_p, _i64p]),
     "mcf_ns_get_arc_upper_bound": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int64)]),
     "mcf_ns_get_metrics": (C.c_int, [C.c_void_p, _P(NsMetrics)]),
+    "mcf_ns_set_pivot_limit": (C.c_int, [C.c_void_p, C.c_int64]),
     "mcf_ns_set_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mcf_ns_get_trace_length": (C.c_int, [C.c_void_p, _P(C.c_int64)]),
     "mcf_ns_begin": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
@@ -170,3 +171,10 @@ def check(rc: int):
 
 def device_count() -> int:
     return lib().mcf_device_count()
+
+
+def comm_unique_id() -> np.ndarray:
+    """128-byte ncclUniqueId (rank 0 creates it, the caller broadcasts it)."""
+    out = np.zeros(128, np.uint8)
+    check(lib().mcf_comm_unique_id(out))
+    return out

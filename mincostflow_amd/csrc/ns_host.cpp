@@ -57,6 +57,7 @@ struct mcf_ns {
     // trace / metrics
     int32_t *trace = nullptr;
     int64_t trace_cap = 0, trace_len = 0;
+    int64_t pivot_limit = 0;          // 0 = none; otherwise Solve() stops after that many pivots with status NotSolved
     mcf_ns_metrics metrics{};
 };
 
@@ -435,7 +436,13 @@ int mcf_ns_set_sharding(mcf_ns *s, const uint8_t id[128], int32_t rank, int32_t 
 {
     if (!s || !id || world < 1 || rank < 0 || rank >= world) return mcf::fail(MCF_ERR_INVALID, "mcf_ns_set_sharding: bad arguments");
     memcpy(s->nccl_id, id, 128);
-    s->rank = rank; s->world = world; s->sharded = world > 1;
+    s->rank = rank; s->world = world; s->sharded = true;   // world 1 still goes through the RCCL exchange (tests)
+    return MCF_OK;
+}
+int mcf_ns_set_pivot_limit(mcf_ns *s, int64_t max_pivots)
+{
+    if (!s || max_pivots < 0) return mcf::fail(MCF_ERR_INVALID, "bad pivot limit");
+    s->pivot_limit = max_pivots;
     return MCF_OK;
 }
 int mcf_ns_set_trace(mcf_ns *s, int32_t *trace, int64_t capacity)
@@ -522,7 +529,11 @@ int mcf_ns_prepare(mcf_ns *s)
     d.block_size = s->block_size;
     d.device = s->device;
     d.flags = s->engine_flags;
-    if (s->sharded) { rc = mcf_shard_range(s->search_arcs, s->rank, s->world, &d.shard_begin, &d.shard_end); if (rc) return rc; }
+    if (s->sharded) {
+        rc = mcf_shard_range(s->search_arcs, s->rank, s->world, &d.shard_begin, &d.shard_end);
+        if (rc) return rc;
+        d.flags |= MCF_ENGINE_DISPATCH;      // the RCCL exchange runs on the engine's stream between the scans
+    }
     if (s->engine) { mcf_engine_destroy(s->engine); s->engine = nullptr; }
     rc = mcf_engine_create(&s->engine, &d);
     if (rc) return rc;
@@ -549,6 +560,7 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
 
     const int64_t max_iter = std::max<int64_t>(1000000, (int64_t)s->n * (int64_t)s->m);   // NS.cs:280
     int64_t it = 0;
+    bool limited = false;
     double t_search = 0, t_tree = 0, t_pot = 0;
     for (;;) {
         const double t0 = mcf::now_ns();
@@ -561,6 +573,7 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         if (s->trace && it < s->trace_cap) s->trace[it] = arc;
         ++it;
         if (it > max_iter) { s->status = MCF_INFEASIBLE; break; }                          // NS.cs:311-317
+        if (s->pivot_limit && it > s->pivot_limit) { --it; limited = true; break; }
         if (pivot(s, arc, &t_tree, &t_pot)) { s->status = MCF_UNBOUNDED; break; }
         const double t1 = mcf::now_ns();
         rc = mcf_engine_patch_state(s->engine, s->n_state, s->st_arc, s->st_val);
@@ -572,7 +585,7 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     mcf_engine_park(s->engine);      // a resident scan grid must not outlive Solve()
     s->trace_len = std::min(it, s->trace_cap);
     s->metrics.iterations = it;
-    if (s->status == MCF_NOT_SOLVED) finish(s);
+    if (s->status == MCF_NOT_SOLVED && !limited) finish(s);
     s->metrics.pivot_search_us = t_search / 1e3;
     s->metrics.tree_update_us = t_tree / 1e3;
     s->metrics.potential_update_us = t_pot / 1e3;

@@ -142,6 +142,9 @@ class NetworkSimplex:
     def set_sharding(self, nccl_id: np.ndarray, rank: int, world: int):
         L.check(L.lib().mcf_ns_set_sharding(self._h, np.ascontiguousarray(nccl_id, np.uint8), rank, world)); return self
 
+    def set_pivot_limit(self, max_pivots: int):
+        L.check(L.lib().mcf_ns_set_pivot_limit(self._h, max_pivots)); return self
+
     def record_trace(self, capacity: int):
         self._trace = np.zeros(max(capacity, 1), np.int32)
         L.check(L.lib().mcf_ns_set_trace(self._h, self._trace.ctypes.data, capacity)); return self

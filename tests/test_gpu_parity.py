@@ -249,6 +249,27 @@ def test_sharded_engines_resolve_like_one_engine(rule, optimized):
                 e.update_potential(nodes, -3)
 
 
+def test_sharded_solve_through_the_rccl_exchange():
+    """mcf_ns_set_sharding + mcf_engine_find_entering_sharded on the one GPU of this box (world size 1: the all-gather
+    and the MINLOC still run); more ranks are covered by tests/test_sharded_gloo.py and the same-device shard test above."""
+    p = load("netgen_8_10a")
+    for sem, rule in [(O.SEM_CSHARP_OPT, O.RULE_BEST), (O.SEM_CSHARP_OPT, O.RULE_BLOCK)]:
+        o = O.Oracle(p, sem, rule)
+        st_o, tr_o = o.solve(trace_cap=1 << 20)
+        ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
+        ns.set_pivot_rule(RULES[rule]).enable_optimized_pivot(True).record_trace(1 << 20)
+        ns.set_sharding(M.comm_unique_id(), 0, 1)
+        assert ns.solve() == st_o == 1
+        assert np.array_equal(ns.trace(), tr_o) and ns.get_total_cost() == o.total_cost
+        assert ns.get_metrics()["engine"]["resident"] == 0         # sharded engines dispatch: the exchange needs the stream
+
+
+def test_pivot_limit_stops_early():
+    p = load("netgen_8_10a")
+    ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply).set_pivot_limit(100)
+    assert ns.solve() == M.SolverStatus.NotSolved and ns.get_metrics()["iterations"] == 100
+
+
 def test_full_size_configs_certified_optimal():
     """BASELINE.json configs 2-4 at full size.  The oracle's Best-Eligible would take minutes here, so parity is checked
     through size-independent properties: the validator's optimality certificate (primal = dual, complementary slackness,
