@@ -233,9 +233,13 @@ def main():
                               "frac": bytes_per_scan / d_avg / HBM_PEAK_GBS,
                               "what": "scan_kernel as one dispatch per search, timed alone with HIP events; an EMPTY dispatch measures ~4 us by this method"}
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")            # PMC pass (rocprofv3 --pmc), see profiles/README.md
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("hbm_bytes_per_scan")
+    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")            # separate rocprofv3 --pmc passes, see profiles/README.md
+    if os.path.exists(tpath) and args.workload == "config3":
+        tj = json.load(open(tpath))
+        if resident:
+            traffic = tj["resident_config3"]["hbm_bytes_per_request"] * requests / max(launches, 1)    # per launch, like achieved
+        else:
+            traffic = tj["scan_dispatch_config3"]["hbm_bytes_per_scan"]
     per = lambda k: sum(m[k] for m in mets) / max(pivots, 1)
     line = {
         "metric": "pivots/sec + solve ms, NETGEN 100k-node/300k-arc; arc-scan GB/s vs HBM peak",
