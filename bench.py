@@ -84,25 +84,39 @@ def cpu_baseline(g, rule, budget_s):
 
 
 def microbench():
-    """Scan-only kernel at sizes where bandwidth, not dispatch latency, decides (SURVEY.md 8d 'scan-only microbenchmark')."""
+    """Scan-only kernel (one dispatch, HIP events) at sizes where bandwidth, not latency, decides.
+    cold = after reading 512 MB of other data (evicts L2 and the 256 MB Infinity Cache)."""
     import numpy as np
 
     import mincostflow_amd as M
     rng = np.random.default_rng(7)
     out = []
-    for m_s, n in ((8_000_000, 1_000_001), (64_000_000, 2_001), (64_000_000, 1_000_001)):
-        a = dict(src=rng.integers(0, n, m_s, dtype=np.int32), tgt=rng.integers(0, n, m_s, dtype=np.int32),
-                 cost=rng.integers(-10 ** 4, 10 ** 4, m_s, dtype=np.int64), state=rng.integers(-1, 2, m_s, dtype=np.int8),
-                 pi=rng.integers(-10 ** 9, 1, n, dtype=np.int64))
-        eng = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible, int_width=64)
-        eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
-        nbytes = eng.stats()["bytes_per_scan"]
+
+    def run(label, n_nodes, m_s, src, tgt, cost, state, pi, endpoints):
+        eng = M.PivotEngine(n_nodes, m_s, m_s, rule=M.PivotRule.BestEligible, int_width=64, flags=M.ENGINE_DISPATCH)
+        eng.upload(src, tgt, cost, state, pi)
+        st = eng.stats()
+        nbytes = st["bytes_per_scan"]
         warm = eng.bench_scan(reps=20)
         cold = eng.bench_scan(reps=8, cold=True, flush_bytes=512 << 20)
-        out.append({"arcs": m_s, "nodes": n, "dtype": "i64", "endpoints": "uniform random", "bytes": nbytes,
+        out.append({"case": label, "arcs": m_s, "nodes": n_nodes, "dtype": "i64", "endpoints": endpoints, "bytes": nbytes,
+                    "grid": f"{st['scan_workgroups']}x{st['scan_threads']}", "potentials_in_lds": n_nodes <= 16384,
                     "warm_us": warm[0] / 1e3, "cold_us": cold[0] / 1e3, "warm_GBs": nbytes / warm[0], "cold_GBs": nbytes / cold[0],
                     "warm_frac_of_hbm_peak": nbytes / warm[0] / HBM_PEAK_GBS, "cold_frac_of_hbm_peak": nbytes / cold[0] / HBM_PEAK_GBS})
-        del eng, a
+
+    for label, m_s, n in (("dense (assignment-like), potentials fit LDS", 64_000_000, 2_001),
+                          ("uniform random end points over 1M nodes (gather worst case)", 64_000_000, 1_000_001)):
+        run(label, n, m_s, rng.integers(0, n, m_s, dtype=np.int32), rng.integers(0, n, m_s, dtype=np.int32),
+            rng.integers(-10 ** 4, 10 ** 4, m_s, dtype=np.int64), rng.integers(-1, 2, m_s, dtype=np.int8),
+            rng.integers(-10 ** 9, 1, n, dtype=np.int64), "uniform random")
+    # BASELINE.json configs[4] as generated: arcs grouped by tail node, random heads
+    g5 = M.netgen_like(SEED, 1_000_000, 8_000_000, 1000, 1000)
+    ns5 = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible)
+    assert ns5.begin() == 0
+    it = ns5.internal()
+    ms = it["search_arc_num"]
+    run("NETGEN-like 1M nodes / 8M arcs start basis (config 5 arrays)", g5.node_count + 1, ms, it["source"][:ms], it["target"][:ms],
+        it["cost"][:ms], it["state"][:ms], it["pi"], "generator order: grouped by tail, random heads")
     return out
 
 

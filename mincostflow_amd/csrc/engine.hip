@@ -34,11 +34,14 @@ namespace {
 constexpr int kThreads = 256;              // 4 wavefronts of 64
 constexpr int kArcsPerThread = 4;          // 16-byte loads of source/target, 4-byte load of state
 constexpr int kTile = kThreads * kArcsPerThread;   // 1024 arcs per workgroup per step
-constexpr int kPad = 4 * kTile;            // device arrays are padded to this with state = 0 (one resident workgroup = 4096 arcs)
+constexpr int kPad = 8 * kTile;            // device arrays are padded to this with state = 0 (two 4096-arc tiles of a 1024-thread workgroup)
 constexpr int kInlinePi = 96;              // potentials patched through the kernel arguments
 constexpr int kInlineState = 4;
-constexpr int kMaxWorkgroups = 2048;
+constexpr int kMaxWorkgroups = 8192;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr int kResidentThreads = 1024;     // 16 wavefronts per workgroup: few pollers, few records (resident and LDS-potential kernels)
+constexpr int kResidentTile = kResidentThreads * kArcsPerThread;   // 4096 arcs per such workgroup
+constexpr int kLdsPiMax = 16384;           // potentials kept in LDS when node_count fits (128 KB of int64): gathers leave the L1/TA path
 
 // 16-byte answer of one workgroup, written with one store into pinned host memory.
 // tag is last so that a host that sees the tag sees the payload (one PCIe write, ascending addresses).
@@ -107,12 +110,24 @@ template <typename T> struct Vec4;
 template <> struct Vec4<int32_t> {
     int32_t v[4];
     __device__ __forceinline__ void load(const int32_t *p) { const int4 a = *reinterpret_cast<const int4 *>(p); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+    __device__ __forceinline__ void load_nt(const int32_t *p)
+    {
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const v4i a = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p));
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    }
 };
 template <> struct Vec4<int64_t> {
     int64_t v[4];
     __device__ __forceinline__ void load(const int64_t *p)
     {
         const longlong2 a = *reinterpret_cast<const longlong2 *>(p), b = *reinterpret_cast<const longlong2 *>(p + 2);
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    }
+    __device__ __forceinline__ void load_nt(const int64_t *p)
+    {
+        typedef long v2l __attribute__((ext_vector_type(2)));
+        const v2l a = __builtin_nontemporal_load(reinterpret_cast<const v2l *>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const v2l *>(p + 2));
         v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
     }
 };
@@ -127,13 +142,20 @@ struct TileData {
     Vec4<T> c;
 };
 
-template <typename T>
+template <typename T, bool NT = false>
 __device__ __forceinline__ void load_tile(const int32_t *src, const int32_t *tgt, const T *cost, const int8_t *state, int i0, TileData<T> &d)
 {
-    d.st4 = *reinterpret_cast<const uint32_t *>(state + i0);
-    d.s.load(src + i0);
-    d.t.load(tgt + i0);
-    d.c.load(cost + i0);
+    if (NT) {   // streamed once per scan: non-temporal, do not displace the potentials from L2
+        d.st4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(state + i0));
+        d.s.load_nt(src + i0);
+        d.t.load_nt(tgt + i0);
+        d.c.load_nt(cost + i0);
+    } else {
+        d.st4 = *reinterpret_cast<const uint32_t *>(state + i0);
+        d.s.load(src + i0);
+        d.t.load(tgt + i0);
+        d.c.load(cost + i0);
+    }
 }
 
 template <typename T, int RULE, bool OPT>
@@ -170,11 +192,11 @@ __device__ __forceinline__ void eval_tile(const TileData<T> &d, const T *pi, int
     }
 }
 
-template <typename T, int RULE, bool OPT>
+template <typename T, int RULE, bool OPT, bool NT = false>
 __device__ __forceinline__ void scan_tile(const ScanParams<T> &p, int i0, Key &best)
 {
     TileData<T> d;
-    load_tile<T>(p.src, p.tgt, p.cost, p.state, i0, d);
+    load_tile<T, NT>(p.src, p.tgt, p.cost, p.state, i0, d);
     eval_tile<T, RULE, OPT>(d, p.pi, p.base + i0, p.m_s, p.next_arc, p.block_size, p.rstar, best);
 }
 
@@ -202,7 +224,7 @@ __device__ __forceinline__ void publish_best(Key best, Slot *slot, uint32_t tag)
     }
 }
 
-template <typename T, int RULE, bool OPT, int UNROLL>
+template <typename T, int RULE, bool OPT, int UNROLL, bool NT = false>
 __global__ __launch_bounds__(kThreads) void scan_kernel(const ScanParams<T> p)
 {
     const int tid = threadIdx.x;
@@ -225,9 +247,44 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(const ScanParams<T> p)
     const int step = gridDim.x * kTile * UNROLL;
     for (int i0 = blockIdx.x * kTile * UNROLL + tid * kArcsPerThread; i0 < p.count_padded; i0 += step) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) scan_tile<T, RULE, OPT>(p, i0 + u * kTile, best);
+        for (int u = 0; u < UNROLL; ++u) scan_tile<T, RULE, OPT, NT>(p, i0 + u * kTile, best);
     }
     publish_best<RULE, false>(best, p.slots + blockIdx.x, p.seq);
+}
+
+// Same scan for graphs whose potential vector fits LDS (node_count <= kLdsPiMax): 1024-thread workgroups copy pi into LDS once
+// and loop over 4096-arc tiles; the two gathers per arc become ds_read instead of divergent vector-memory loads, which
+// otherwise cap the scan at about one lane per clock per CU even when every gather hits L1.
+template <typename T, int RULE, bool OPT, int UNROLL>
+__global__ __launch_bounds__(kResidentThreads) void scan_kernel_lds(const ScanParams<T> p, int n_nodes)
+{
+    __shared__ __attribute__((aligned(16))) T lpi[kLdsPiMax];
+    const int tid = threadIdx.x;
+    if (p.n_pi | p.n_st) {
+        if (tid < p.n_pi) p.pi[p.pi_node[tid]] = p.pi_val[tid];
+        if (tid >= kResidentThreads - kInlineState && tid - (kResidentThreads - kInlineState) < p.n_st) {
+            const int k = tid - (kResidentThreads - kInlineState);
+            const int a = p.st_arc[k] - p.base;
+            if ((unsigned)a < (unsigned)p.count_padded) p.state[a] = (int8_t)p.st_val[k];
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    }
+    for (int i = tid; i < n_nodes; i += kResidentThreads) lpi[i] = p.pi[i];
+    __syncthreads();
+    Key best;
+    best.c = 0;
+    best.r = kNone;
+    best.p = kNone;
+    const int step = gridDim.x * UNROLL * kResidentTile;     // UNROLL tiles per step: all their streamed loads are in flight together
+    for (int i0 = blockIdx.x * UNROLL * kResidentTile + tid * kArcsPerThread; i0 < p.count_padded; i0 += step) {
+        TileData<T> d[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) load_tile<T>(p.src, p.tgt, p.cost, p.state, i0 + u * kResidentTile, d[u]);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) eval_tile<T, RULE, OPT>(d[u], lpi, p.base + i0 + u * kResidentTile, p.m_s, p.next_arc, p.block_size, p.rstar, best);
+    }
+    publish_best<RULE, false, kResidentThreads>(best, p.slots + blockIdx.x, p.seq);
 }
 
 // ------------------------------------------------------------------------------------------------ resident mode
@@ -241,12 +298,10 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(const ScanParams<T> p)
 //   line 0      [0] seq [1] cmd (0 scan, 1 quit) [2] next_arc [3] rstar [4] n_pi [5] n_st [6+2k] state arc k [7+2k] state value k
 //   line 1..63  five patches {node, value lo, value hi} each
 // Every spin is bounded by s_memrealtime (100 MHz): a resident grid that hears nothing for idle_ticks exits by itself.
-constexpr int kMailboxLines = 1024;               // lines staged in LDS at a time: 64 KB = line 0 + a chunk of 1023 patch lines (5115 patches)
+constexpr int kMailboxLines = 256;                // lines staged in LDS at a time: 16 KB = line 0 + a chunk of 255 patch lines (1275 patches)
 constexpr int kMailboxPatchesPerLine = 5;
 constexpr int kChunkLines = kMailboxLines - 1;
 constexpr int kResidentMaxState = 2;
-constexpr int kResidentThreads = 1024;                                          // 16 wavefronts: few pollers, few records
-constexpr int kResidentTile = kResidentThreads * kArcsPerThread;                // 4096 arcs per workgroup
 
 template <typename T>
 struct ResidentParams {
@@ -283,15 +338,21 @@ __device__ __forceinline__ void resident_exit(uint32_t *exit_word, uint32_t code
 //   line 0      [0] seq [1] cmd (0 scan, 1 quit) [2] next_arc [3] rstar [4] n_pi [5] n_st [6..9] two {arc, state} [10..12] patch 0 {node, lo, hi}
 //   line 1..63  five patches {node, value lo, value hi} each (patches 1..n_pi-1)
 // The poll reads line 0 only (one 64-byte read per workgroup per poll); the other lines are fetched when n_pi > 1.
-template <typename T, int RULE, bool OPT, bool REG>
+template <typename T, int RULE, bool OPT, bool REG, bool LPI>
 __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const ResidentParams<T> p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lm[kMailboxLines * 16];
+    __shared__ __attribute__((aligned(16))) T lpi[LPI ? kLdsPiMax : 2];      // LPI: the whole potential vector lives here
     __shared__ uint32_t s_timeout;
     const int tid = threadIdx.x;
     const int my_i0 = blockIdx.x * kResidentTile + tid * kArcsPerThread;
     TileData<T> mine;
     if (REG) load_tile<T>(p.src, p.tgt, p.cost, p.state, my_i0, mine);
+    if (LPI) {
+        for (int i = tid; i < p.max_pi; i += kResidentThreads) lpi[i] = p.pi[i];
+        __syncthreads();
+    }
+    const T *const pi_view = LPI ? lpi : p.pi;
     uint32_t last = p.start_seq, served = 0;
     uint64_t scan_ticks = 0;
     uint64_t idle_since = __builtin_amdgcn_s_memrealtime();
@@ -328,7 +389,7 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
             return;
         }
         // ---- patches: final values, applied by EVERY workgroup before it reads (same argument as scan_kernel).
-        // Patch 0 rides in the header; the rest comes in chunks of 1023 lines (one is enough for 5115 patches), each line verified by its tag.
+        // Patch 0 rides in the header; the rest comes in chunks of 255 lines (1275 patches), each line verified by its tag.
         bool torn = false;
         for (int first = 1; first < lines; first += kChunkLines) {
             const int chunk = lines - first < kChunkLines ? lines - first : kChunkLines;
@@ -341,7 +402,8 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
                     const int c = tid + k * kResidentThreads;
                     if (c < chunk * 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x[k]) : "v"(p.mailbox + ((size_t)first * 16 + c * 4)) : "memory");
                 }
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])::"memory");
+                static_assert(kMailboxLines * 4 / kResidentThreads == 1, "one 16-byte read per thread and chunk");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0])::"memory");
 #pragma unroll
                 for (int k = 0; k < kMailboxLines * 4 / kResidentThreads; ++k) {
                     const int c = tid + k * kResidentThreads;
@@ -359,12 +421,13 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
                 const uint32_t *q = lm + (1 + rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
                 const int64_t v = (int64_t)(((uint64_t)q[2] << 32) | q[1]);
                 p.pi[q[0]] = (T)v;
+                if (LPI) lpi[q[0]] = (T)v;
             }
             __syncthreads();                               // the chunk has been consumed before the next one lands in lm
         }
         if (torn) continue;                                // a line was still in flight: poll again (re-applying final values is harmless)
         if (n_pi | n_st) {
-            if (tid == 0 && n_pi > 0) p.pi[p0_node] = (T)(int64_t)(((uint64_t)p0_hi << 32) | p0_lo);
+            if (tid == 0 && n_pi > 0) { const T v0 = (T)(int64_t)(((uint64_t)p0_hi << 32) | p0_lo); p.pi[p0_node] = v0; if (LPI) lpi[p0_node] = v0; }
             if (tid == 64 && n_st > 0) { const int a = st_arc0 - p.base; if ((unsigned)a < (unsigned)p.count_padded) p.state[a] = (int8_t)st_val0; }
             if (tid == 65 && n_st > 1) { const int a = st_arc1 - p.base; if ((unsigned)a < (unsigned)p.count_padded) p.state[a] = (int8_t)st_val1; }
             if (REG) {
@@ -380,12 +443,12 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
         best.r = kNone;
         best.p = kNone;
         if (REG) {
-            eval_tile<T, RULE, OPT>(mine, p.pi, p.base + my_i0, p.m_s, next_arc, p.block_size, rstar, best);
+            eval_tile<T, RULE, OPT>(mine, pi_view, p.base + my_i0, p.m_s, next_arc, p.block_size, rstar, best);
         } else {
             for (int i0 = my_i0; i0 < p.count_padded; i0 += gridDim.x * kResidentTile) {
                 TileData<T> d;
                 load_tile<T>(p.src, p.tgt, p.cost, p.state, i0, d);
-                eval_tile<T, RULE, OPT>(d, p.pi, p.base + i0, p.m_s, next_arc, p.block_size, rstar, best);
+                eval_tile<T, RULE, OPT>(d, pi_view, p.base + i0, p.m_s, next_arc, p.block_size, rstar, best);
             }
         }
         publish_best<RULE, true, kResidentThreads>(best, p.slots + blockIdx.x, seq);
@@ -411,11 +474,15 @@ __global__ __launch_bounds__(kThreads) void update_kernel(T *pi, const int32_t *
     }
 }
 
+// evicts the caches before a "cold" measurement: reads a large buffer once (no stores, so no dirty lines are left to write back
+// during the measured scan); the sum is kept alive through a store that practically never happens
 __global__ void flush_kernel(uint4 *buf, size_t n16)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n16; i += stride) { uint4 v = buf[i]; v.x += 1; buf[i] = v; }
+    unsigned acc = 0;
+    for (; i < n16; i += stride) { const uint4 v = buf[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x9E3779B9u) buf[0].x = acc;
 }
 
 #define HIP_TRY(expr)                                                                                      \
@@ -474,6 +541,9 @@ struct mcf_engine {
     int8_t *d_state = nullptr;
     Slot *h_slots = nullptr, *d_slots = nullptr;    // pinned host memory and its device alias
     int grid = 0, unroll = 1;
+    bool nt = false;
+    bool lds_pi = false;           // node_count <= kLdsPiMax: kernels keep the potentials in LDS
+    int lds_grid = 0;
     uint32_t seq = 0;
     bool uploaded = false;
     // host mirror of pi: patches carry final values
@@ -564,17 +634,31 @@ void fill_params(mcf_engine *e, ScanParams<T> &p, bool with_patches)
     }
 }
 
+template <typename T, int RULE, bool OPT, int UNROLL, bool NT>
+void launch_scan_k(mcf_engine *e, const ScanParams<T> &p, hipEvent_t start, hipEvent_t stop)
+{
+    const dim3 grid(e->grid), block(kThreads);
+    if (start) hipExtLaunchKernelGGL((scan_kernel<T, RULE, OPT, UNROLL, NT>), grid, block, 0, e->stream, start, stop, 0, p);
+    else hipLaunchKernelGGL((scan_kernel<T, RULE, OPT, UNROLL, NT>), grid, block, 0, e->stream, p);
+}
+
 template <typename T, int RULE, bool OPT>
 void launch_scan_u(mcf_engine *e, const ScanParams<T> &p, hipEvent_t start, hipEvent_t stop)
 {
-    const dim3 grid(e->grid), block(kThreads);
-    if (e->unroll == 2) {
-        if (start) hipExtLaunchKernelGGL((scan_kernel<T, RULE, OPT, 2>), grid, block, 0, e->stream, start, stop, 0, p);
-        else hipLaunchKernelGGL((scan_kernel<T, RULE, OPT, 2>), grid, block, 0, e->stream, p);
-    } else {
-        if (start) hipExtLaunchKernelGGL((scan_kernel<T, RULE, OPT, 1>), grid, block, 0, e->stream, start, stop, 0, p);
-        else hipLaunchKernelGGL((scan_kernel<T, RULE, OPT, 1>), grid, block, 0, e->stream, p);
+    if (e->lds_pi) {
+        const dim3 grid(e->grid), block(kResidentThreads);
+        if (e->unroll >= 2) {
+            if (start) hipExtLaunchKernelGGL((scan_kernel_lds<T, RULE, OPT, 2>), grid, block, 0, e->stream, start, stop, 0, p, e->d.node_count);
+            else hipLaunchKernelGGL((scan_kernel_lds<T, RULE, OPT, 2>), grid, block, 0, e->stream, p, e->d.node_count);
+        } else {
+            if (start) hipExtLaunchKernelGGL((scan_kernel_lds<T, RULE, OPT, 1>), grid, block, 0, e->stream, start, stop, 0, p, e->d.node_count);
+            else hipLaunchKernelGGL((scan_kernel_lds<T, RULE, OPT, 1>), grid, block, 0, e->stream, p, e->d.node_count);
+        }
+        return;
     }
+    if (e->unroll == 4) { if (e->nt) launch_scan_k<T, RULE, OPT, 4, true>(e, p, start, stop); else launch_scan_k<T, RULE, OPT, 4, false>(e, p, start, stop); }
+    else if (e->unroll == 2) { if (e->nt) launch_scan_k<T, RULE, OPT, 2, true>(e, p, start, stop); else launch_scan_k<T, RULE, OPT, 2, false>(e, p, start, stop); }
+    else launch_scan_k<T, RULE, OPT, 1, false>(e, p, start, stop);
 }
 
 template <typename T>
@@ -697,8 +781,11 @@ template <typename T, int RULE, bool OPT>
 void launch_resident_r(mcf_engine *e, const ResidentParams<T> &p)
 {
     const dim3 grid(e->res_grid), block(kResidentThreads);
-    if (e->resident_reg) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
-    else hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    const bool lpi = e->lds_pi;
+    if (e->resident_reg && lpi) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    else if (e->resident_reg) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    else if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    else hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
 }
 
 template <typename T>
@@ -1008,9 +1095,20 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
     e->count_padded = std::max(kPad, (count + kPad - 1) / kPad * kPad);
     e->block_size = desc->block_size > 0 ? desc->block_size : mcf::default_block_size(desc->search_arc_num, desc->semantics);
     e->unroll = count > (1 << 20) ? 2 : 1;
+    if (const char *u = getenv("MCF_HIP_UNROLL")) { const int v = atoi(u); if (v == 1 || v == 2 || v == 4) e->unroll = v; }
+    if (const char *u = getenv("MCF_HIP_NT")) e->nt = u[0] == '1';
+    int max_wg = 2048;
+    if (const char *u = getenv("MCF_HIP_MAXWG")) { const int v = atoi(u); if (v >= 1 && v <= kMaxWorkgroups) max_wg = v; }
     const int groups = e->count_padded / (kTile * e->unroll);
-    e->grid = desc->scan_workgroups > 0 ? std::min(desc->scan_workgroups, kMaxWorkgroups) : std::min(groups, kMaxWorkgroups);
+    e->grid = desc->scan_workgroups > 0 ? std::min(desc->scan_workgroups, kMaxWorkgroups) : std::min(groups, max_wg);
     e->grid = std::max(1, std::min(e->grid, groups));
+    e->lds_pi = desc->node_count <= kLdsPiMax && !(getenv("MCF_HIP_LDS_PI") && getenv("MCF_HIP_LDS_PI")[0] == '0');
+    if (e->lds_pi) {
+        // one 1024-thread workgroup per CU (the 128 KB potential copy allows no more); each loops over its 4096-arc tiles
+        e->unroll = count > (2 << 20) ? 2 : 1;
+        const int tiles = e->count_padded / (e->unroll * kResidentTile);
+        e->grid = std::max(1, std::min(tiles, desc->scan_workgroups > 0 ? desc->scan_workgroups : 256));
+    }
     const size_t w = desc->int_width / 8;
     hipError_t err = hipSuccess;
     auto chk = [&](hipError_t x) { if (err == hipSuccess && x != hipSuccess) err = x; };
@@ -1070,7 +1168,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         }
     }
     e->st.scan_workgroups = e->resident_ok ? e->res_grid : e->grid;
-    e->st.scan_threads = e->resident_ok ? kResidentThreads : kThreads;
+    e->st.scan_threads = (e->resident_ok || e->lds_pi) ? kResidentThreads : kThreads;
     e->st.resident = e->resident_ok ? 1 : 0;
     e->st.bytes_per_scan = (int64_t)(desc->int_width == 64 ? 17 : 13) * count + (int64_t)w * desc->node_count;
     *out = e;
