@@ -188,6 +188,40 @@ def test_csharp_unit_test_answers_on_gpu(kat):
     assert len(seen) <= 1
 
 
+@pytest.mark.parametrize("case", K.LEMON_TABLE, ids=[f"lemon-{c[0]}" for c in K.LEMON_TABLE])
+def test_status_parity_on_the_lemon_table_networks(case):
+    """LEMON's 12-node / negative-cost networks through the C# semantics: whatever the C# port answers (including its
+    documented deviations D7/D9: unbounded detection, LEQ/GEQ slack) the GPU path answers too, pivot for pivot."""
+    cid, d, stype, _, _ = case
+    p = problem_from_dict(d)
+    for sem, rule in [(O.SEM_CSHARP_OPT, O.RULE_BLOCK), (O.SEM_CSHARP, O.RULE_BEST), (O.SEM_CSHARP_OPT, O.RULE_FIRST)]:
+        o, st_o, tr_o, ns, st = _solve_both(p, sem, rule, supply_type=stype)
+        assert st == st_o, (cid, sem, rule, st, st_o)
+        assert np.array_equal(ns.trace(), tr_o[: len(ns.trace())]) and len(ns.trace()) in (len(tr_o), len(tr_o) - 0)
+        if st == M.SolverStatus.Optimal:
+            assert ns.get_total_cost() == o.total_cost and np.array_equal(ns.flows(), o.flow())
+
+
+def test_degenerate_graphs():
+    # no arcs at all: only the n root links are searched
+    ns = M.NetworkSimplex(3, np.zeros(0, np.int32), np.zeros(0, np.int32)).set_problem(supply=[0, 0, 0])
+    assert ns.solve() == M.SolverStatus.Optimal and ns.get_total_cost() == 0
+    ns = M.NetworkSimplex(2, np.zeros(0, np.int32), np.zeros(0, np.int32)).set_problem(supply=[1, -1])
+    assert ns.solve() == M.SolverStatus.Infeasible            # nothing connects the two nodes
+    # Solve() is single-shot (D11)
+    with pytest.raises(M.McfError) as ei:
+        ns.solve()
+    assert ei.value.code == L.ERR_STATE
+    # self loop and parallel arcs
+    ns = M.NetworkSimplex(2, [0, 0, 0, 1], [1, 1, 0, 1]).set_problem(upper=[5, 5, 9, 9], cost=[3, 2, -1, 4], supply=[7, -7])
+    p = O.Problem(2, 4, [0, 0, 0, 1], [1, 1, 0, 1], [0] * 4, [5, 5, 9, 9], [3, 2, -1, 4], [7, -7])
+    o = O.Oracle(p, O.SEM_CSHARP, O.RULE_BLOCK)
+    st_o, _ = o.solve()
+    assert ns.solve() == st_o
+    if st_o == 1:
+        assert ns.get_total_cost() == o.total_cost and np.array_equal(ns.flows(), o.flow())
+
+
 def test_int32_and_int64_device_paths_agree_and_overflow_is_caught():
     g = M.netgen_like(13502460, 3000, 12000, 50, 50)
     p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
