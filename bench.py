@@ -287,6 +287,16 @@ def main():
     }
     if sharded is not None:
         line["sharded"] = sharded
+    if args.gpus == 1 and rule == M.PivotRule.BestEligible:
+        # extra, NOT the headline: MCF_ENGINE_CANDIDATES -- the device search also returns a candidate list that is complete below a
+        # threshold and the host answers the following searches from it whenever that provably is the scan's answer (same pivots)
+        nc = M.NetworkSimplex.from_problem(g).set_pivot_rule(rule).enable_optimized_pivot(True).set_device(local_rank, width, 0, M.ENGINE_CANDIDATES).prepare()
+        assert nc.solve() == M.SolverStatus.Optimal and nc.get_total_cost() == cost
+        mc = nc.get_metrics()
+        line["candidate_cache"] = {"pivots_per_s": mc["iterations"] / (mc["loop_us"] / 1e6), "solve_ms": mc["loop_us"] / 1e3, "pivots": mc["iterations"],
+                                   "device_searches": mc["engine"]["resident_requests"], "host_answered": mc["engine"]["host_decided"],
+                                   "identical_pivot_sequence": mc["iterations"] == mets[0]["iterations"]}
+        del nc
     if args.concurrent > 1 and args.gpus == 1:
         # throughput mode: several independent instances in flight on ONE GPU (one host thread, stream and resident grid each);
         # the per-pivot host <-> device latency of one solve is hidden behind the others.  Not the headline: solve latency is unchanged.

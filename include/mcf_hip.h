@@ -99,6 +99,10 @@ typedef struct mcf_engine_desc {
 #define MCF_ENGINE_NO_INLINE_UPDATE 4     /* always apply patches with the separate update kernel */
 #define MCF_ENGINE_RESIDENT 8             /* (default behaviour, kept for explicitness) serve searches from ONE resident scan grid fed
                                              through a mailbox in BAR-mapped VRAM instead of one dispatch per search */
+#define MCF_ENGINE_CANDIDATES 32          /* Best Eligible, resident mode, <= 1M search arcs: every device search also returns a candidate
+                                             list that is complete below a threshold; the following searches are answered on the host
+                                             from that list plus the few arcs the pivots touched, whenever that provably is the scan's
+                                             answer (identical pivot sequence, fewer round trips).  Off by default. */
 #define MCF_ENGINE_DISPATCH 16            /* one scan dispatch per search.  Also what an engine falls back to when it is sharded, when
                                              kernel timing flags are set, or when the platform has no host-writable VRAM.
                                              The environment variable MCF_HIP_RESIDENT=0/1 overrides the choice. */
@@ -178,6 +182,8 @@ typedef struct mcf_engine_stats {
     int64_t resident_requests;    /* searches it served */
     double resident_scan_ns;      /* device clock: request seen -> record published, workgroup 0, summed over requests */
     double resident_kernel_ns;    /* HIP-event residency time of those dispatches */
+    int64_t candidates;           /* 1 when the candidate cache is active */
+    int64_t host_decided;         /* searches answered from the candidate list without a device request */
 } mcf_engine_stats;
 MCF_API int mcf_engine_get_stats(mcf_engine *e, mcf_engine_stats *out);
 MCF_API int mcf_engine_reset_stats(mcf_engine *e);

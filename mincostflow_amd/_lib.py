@@ -20,7 +20,7 @@ SUPPLY_GEQ, SUPPLY_LEQ = 0, 1
 NOT_SOLVED, OPTIMAL, INFEASIBLE, UNBOUNDED, UNBALANCED = 0, 1, 2, 3, 4
 STATE_UPPER, STATE_TREE, STATE_LOWER = -1, 0, 1
 INF_CAP = np.iinfo(np.int64).max
-ENGINE_SAMPLE_KERNEL_TIME, ENGINE_TIME_EVERY_KERNEL, ENGINE_NO_INLINE_UPDATE, ENGINE_RESIDENT, ENGINE_DISPATCH = 1, 2, 4, 8, 16
+ENGINE_SAMPLE_KERNEL_TIME, ENGINE_TIME_EVERY_KERNEL, ENGINE_NO_INLINE_UPDATE, ENGINE_RESIDENT, ENGINE_DISPATCH, ENGINE_CANDIDATES = 1, 2, 4, 8, 16, 32
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OVERFLOW, ERR_TIMEOUT, ERR_STATE, ERR_IO, ERR_COMM = -1, -2, -3, -4, -5, -6, -7, -8
 
 
@@ -45,7 +45,8 @@ class EngineStats(C.Structure):
                 ("timed_scans", C.c_int64), ("timed_scan_ns", C.c_double), ("host_wait_ns", C.c_double),
                 ("host_launch_ns", C.c_double), ("scan_workgroups", C.c_int32), ("scan_threads", C.c_int32),
                 ("bytes_per_scan", C.c_int64), ("resident", C.c_int64), ("resident_launches", C.c_int64),
-                ("resident_requests", C.c_int64), ("resident_scan_ns", C.c_double), ("resident_kernel_ns", C.c_double)]
+                ("resident_requests", C.c_int64), ("resident_scan_ns", C.c_double), ("resident_kernel_ns", C.c_double), ("candidates", C.c_int64),
+                ("host_decided", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -294,10 +294,6 @@ __global__ __launch_bounds__(kResidentThreads) void scan_kernel_lds(const ScanPa
 // memory, applies the patches, scans the tile(s) it owns and answers with its 16-byte record in pinned host memory.
 // Workgroups that own a single tile keep its arcs in registers (REG), so a request costs two potential gathers per arc and nothing else.
 //
-// Mailbox: 64 lines of 64 bytes; dword 15 of EVERY line repeats seq, so a torn read of any line is detected and retried.
-//   line 0      [0] seq [1] cmd (0 scan, 1 quit) [2] next_arc [3] rstar [4] n_pi [5] n_st [6+2k] state arc k [7+2k] state value k
-//   line 1..63  five patches {node, value lo, value hi} each
-// Every spin is bounded by s_memrealtime (100 MHz): a resident grid that hears nothing for idle_ticks exits by itself.
 constexpr int kMailboxLines = 256;                // lines staged in LDS at a time: 16 KB = line 0 + a chunk of 255 patch lines (1275 patches)
 constexpr int kMailboxPatchesPerLine = 5;
 constexpr int kChunkLines = kMailboxLines - 1;
@@ -315,7 +311,8 @@ struct ResidentParams {
     uint32_t *exit_word;        // pinned host memory: [0] exit code, [1] requests served, [2..3] scan ticks of workgroup 0
     int32_t base, count_padded, m_s, block_size;
     uint32_t start_seq, idle_ticks;
-    int32_t max_pi;             // patches the mailbox can hold (= node_count)
+    int32_t max_pi;             // potential patches the mailbox can hold (= node_count)
+    int32_t max_st;             // state patches it can hold
 };
 
 __device__ __forceinline__ void mailbox_load16(const uint32_t *src, uint32_t *lds_dst)
@@ -334,11 +331,112 @@ __device__ __forceinline__ void resident_exit(uint32_t *exit_word, uint32_t code
     __hip_atomic_store(exit_word, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Mailbox: 64 lines of 64 bytes; dword 15 of EVERY line repeats seq, so a torn read of any line is detected and retried.
-//   line 0      [0] seq [1] cmd (0 scan, 1 quit) [2] next_arc [3] rstar [4] n_pi [5] n_st [6..9] two {arc, state} [10..12] patch 0 {node, lo, hi}
-//   line 1..63  five patches {node, value lo, value hi} each (patches 1..n_pi-1)
-// The poll reads line 0 only (one 64-byte read per workgroup per poll); the other lines are fetched when n_pi > 1.
-template <typename T, int RULE, bool OPT, bool REG, bool LPI>
+// (c, p) lexicographic; {0, kNone} = "none" and loses against every eligible arc
+struct Cand { int64_t c; uint32_t p; };
+__device__ __forceinline__ bool cand_less(int64_t c1, uint32_t p1, int64_t c2, uint32_t p2) { return c1 < c2 || (c1 == c2 && p1 < p2); }
+__device__ __forceinline__ void cand_wave_min(int64_t &c, uint32_t &p)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int64_t oc = __shfl_xor(c, off, 64);
+        const uint32_t op = __shfl_xor(p, off, 64);
+        const bool take = cand_less(oc, op, c, p);
+        c = take ? oc : c;
+        p = take ? op : p;
+    }
+}
+__device__ __forceinline__ void store_record_system(Slot *slot, int64_t c, uint32_t p, uint32_t tag)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    v4u out;
+    out.x = (uint32_t)(uint64_t)c;
+    out.y = (uint32_t)((uint64_t)c >> 32);
+    out.z = p;
+    out.w = tag;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(slot), "v"(out) : "memory");
+}
+
+// Best Eligible with candidates (CAND): besides its best arc a workgroup reports up to three more candidates and a THRESHOLD
+// = the smallest key among all of its eligible arcs that it does NOT report.  The host can then serve the following pivots
+// from the candidate list as long as the answer provably is on it (mcf_engine.cand_* in the host code) -- same pivots, fewer
+// round trips.  Per thread: best and second best of its 4 arcs; per wave: two butterflies give the wave's best and its exact
+// second best; thread 0 keeps the 4 best of the 16 wave winners and folds everything else into the threshold.
+constexpr int kCandPerGroup = 4;
+constexpr int kCandRecords = 8;        // record stride per workgroup in candidate mode: 4 candidates, 1 threshold, 3 unused
+
+template <typename T>
+__device__ __forceinline__ void eval_tile_best2(const TileData<T> &d, const T *pi, int e0, int64_t &c1, uint32_t &p1, int64_t &c2, uint32_t &p2)
+{
+    T ps[4], pt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ps[j] = pi[d.s.v[j]]; pt[j] = pi[d.t.v[j]]; }
+    c1 = 0; p1 = kNone; c2 = 0; p2 = kNone;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int st = (int)(int8_t)(d.st4 >> (8 * j));
+        const int64_t dd = (int64_t)d.c.v[j] + (int64_t)ps[j] - (int64_t)pt[j];
+        const int64_t rc = st > 0 ? dd : (st < 0 ? -dd : 0);
+        const uint32_t e = (uint32_t)(e0 + j);
+        const bool elig = rc < 0;
+        const bool b1 = elig && cand_less(rc, e, c1, p1);
+        const bool b2 = elig && !b1 && cand_less(rc, e, c2, p2);
+        // new best pushes the old best down to second
+        c2 = b1 ? c1 : (b2 ? rc : c2);
+        p2 = b1 ? p1 : (b2 ? e : p2);
+        c1 = b1 ? rc : c1;
+        p1 = b1 ? e : p1;
+    }
+}
+
+__device__ __forceinline__ void publish_candidates(int64_t c1, uint32_t p1, int64_t c2, uint32_t p2, Slot *slots, uint32_t tag)
+{
+    const int tid = threadIdx.x;
+    __shared__ Cand wave_first[kResidentThreads / 64], wave_second[kResidentThreads / 64];
+    int64_t wc = c1;
+    uint32_t wp = p1;
+    cand_wave_min(wc, wp);                                   // the wave's best
+    int64_t sc = (p1 == wp && p1 != kNone) ? c2 : c1;        // the winner lane now offers its second best
+    uint32_t sp = (p1 == wp && p1 != kNone) ? p2 : p1;
+    cand_wave_min(sc, sp);                                   // the wave's exact second best
+    if ((tid & 63) == 0) { wave_first[tid >> 6] = Cand{wc, wp}; wave_second[tid >> 6] = Cand{sc, sp}; }
+    __syncthreads();
+    if (tid == 0) {
+        int64_t kc[kCandPerGroup];
+        uint32_t kp[kCandPerGroup];
+#pragma unroll
+        for (int k = 0; k < kCandPerGroup; ++k) { kc[k] = 0; kp[k] = kNone; }
+        int64_t tc = 0;
+        uint32_t tp = kNone;                                 // threshold
+        for (int w = 0; w < kResidentThreads / 64; ++w) {
+            int64_t c = wave_first[w].c;
+            uint32_t q = wave_first[w].p;
+            // insert (c, q) into the sorted top 4; whatever falls off goes to the threshold
+#pragma unroll
+            for (int k = 0; k < kCandPerGroup; ++k) {
+                const bool sw = cand_less(c, q, kc[k], kp[k]);
+                const int64_t oc = kc[k];
+                const uint32_t op = kp[k];
+                kc[k] = sw ? c : kc[k];
+                kp[k] = sw ? q : kp[k];
+                c = sw ? oc : c;
+                q = sw ? op : q;
+            }
+            if (cand_less(c, q, tc, tp)) { tc = c; tp = q; }
+            if (cand_less(wave_second[w].c, wave_second[w].p, tc, tp)) { tc = wave_second[w].c; tp = wave_second[w].p; }
+        }
+        Slot *out = slots + (size_t)blockIdx.x * kCandRecords;
+#pragma unroll
+        for (int k = 0; k < kCandPerGroup; ++k) store_record_system(out + k, kc[k], kp[k], tag);
+        store_record_system(out + kCandPerGroup, tc, tp, tag);
+    }
+}
+
+// Mailbox: lines of 64 bytes; dword 15 of EVERY line repeats seq, so a torn read of any line is detected and retried.
+//   line 0      [0] seq [1] cmd (0 scan, 1 quit) [2] next_arc [3] rstar [4] n_pi [5] n_st [6..9] state patches 0,1 {arc, value}
+//               [10..12] potential patch 0 {node, lo, hi}
+//   line 1..    five entries {a, b, c} each: potential patches 1..n_pi-1 {node, lo, hi}, then state patches 2..n_st-1 {arc, value, 0}
+// The poll reads line 0 only (one 64-byte read per workgroup per poll); the other lines are fetched when there are more entries.
+template <typename T, int RULE, bool OPT, bool REG, bool LPI, bool CAND>
 __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const ResidentParams<T> p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lm[kMailboxLines * 16];
@@ -362,15 +460,16 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
         if (tid == 0) s_timeout = (__builtin_amdgcn_s_memrealtime() - idle_since > p.idle_ticks) ? 1u : 0u;
         __syncthreads();
         const uint32_t seq = lm[0];
-        int n_pi = (int)lm[4];
+        int n_pi = (int)lm[4], n_st = (int)lm[5];
         n_pi = n_pi < 0 ? 0 : (n_pi > p.max_pi ? p.max_pi : n_pi);
-        const int lines = n_pi <= 1 ? 1 : 1 + (n_pi - 1 + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
+        n_st = n_st < 0 ? 0 : (n_st > p.max_st ? p.max_st : n_st);
+        const int extra_pi = n_pi > 1 ? n_pi - 1 : 0, extra_st = n_st > 2 ? n_st - 2 : 0;
+        const int entries = extra_pi + extra_st;
+        const int lines = 1 + (entries + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
         const bool ok = seq != last && lm[15] == seq;
         const bool timed_out = s_timeout != 0;
         const uint32_t cmd = lm[1];
         const int next_arc = (int)lm[2], rstar = (int)lm[3];
-        int n_st = (int)lm[5];
-        n_st = n_st < 0 ? 0 : (n_st > kResidentMaxState ? kResidentMaxState : n_st);
         const int st_arc0 = (int)lm[6], st_arc1 = (int)lm[8];
         const uint32_t st_val0 = lm[7], st_val1 = lm[9];
         const uint32_t p0_node = lm[10], p0_lo = lm[11], p0_hi = lm[12];
@@ -389,39 +488,44 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
             return;
         }
         // ---- patches: final values, applied by EVERY workgroup before it reads (same argument as scan_kernel).
-        // Patch 0 rides in the header; the rest comes in chunks of 255 lines (1275 patches), each line verified by its tag.
+        // The entries beyond the header come in chunks of 255 lines (1275 entries), each line verified by its tag before use.
         bool torn = false;
         for (int first = 1; first < lines; first += kChunkLines) {
             const int chunk = lines - first < kChunkLines ? lines - first : kChunkLines;
-            {   // all of a thread's (up to four) 16-byte reads are in flight together; one wait, then LDS
+            {
                 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                v4u x[kMailboxLines * 4 / kResidentThreads];
-#pragma unroll
-                for (int k = 0; k < kMailboxLines * 4 / kResidentThreads; ++k) {
-                    x[k] = v4u{0u, 0u, 0u, 0u};
-                    const int c = tid + k * kResidentThreads;
-                    if (c < chunk * 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x[k]) : "v"(p.mailbox + ((size_t)first * 16 + c * 4)) : "memory");
-                }
                 static_assert(kMailboxLines * 4 / kResidentThreads == 1, "one 16-byte read per thread and chunk");
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0])::"memory");
-#pragma unroll
-                for (int k = 0; k < kMailboxLines * 4 / kResidentThreads; ++k) {
-                    const int c = tid + k * kResidentThreads;
-                    if (c < chunk * 4) *reinterpret_cast<v4u *>(lm + 16 + c * 4) = x[k];
-                }
+                v4u x = v4u{0u, 0u, 0u, 0u};
+                if (tid < chunk * 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x) : "v"(p.mailbox + ((size_t)first * 16 + tid * 4)) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)::"memory");
+                if (tid < chunk * 4) *reinterpret_cast<v4u *>(lm + 16 + tid * 4) = x;
             }
             __syncthreads();
             int bad = 0;
             for (int l = tid; l < chunk; l += kResidentThreads) bad |= (lm[(1 + l) * 16 + 15] != seq);
             if (__syncthreads_or(bad)) { torn = true; break; }
-            const int i_lo = 1 + (first - 1) * kMailboxPatchesPerLine;
-            const int i_hi = n_pi < i_lo + chunk * kMailboxPatchesPerLine ? n_pi : i_lo + chunk * kMailboxPatchesPerLine;
+            const int i_lo = (first - 1) * kMailboxPatchesPerLine;                    // entry index of the chunk's first entry
+            const int i_hi = entries < i_lo + chunk * kMailboxPatchesPerLine ? entries : i_lo + chunk * kMailboxPatchesPerLine;
             for (int i = i_lo + tid; i < i_hi; i += kResidentThreads) {
                 const int rel = i - i_lo;
                 const uint32_t *q = lm + (1 + rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
-                const int64_t v = (int64_t)(((uint64_t)q[2] << 32) | q[1]);
-                p.pi[q[0]] = (T)v;
-                if (LPI) lpi[q[0]] = (T)v;
+                if (i < extra_pi) {
+                    const int64_t v = (int64_t)(((uint64_t)q[2] << 32) | q[1]);
+                    p.pi[q[0]] = (T)v;
+                    if (LPI) lpi[q[0]] = (T)v;
+                } else {
+                    const int a = (int)q[0] - p.base;
+                    if ((unsigned)a < (unsigned)p.count_padded) p.state[a] = (int8_t)q[1];
+                }
+            }
+            if (REG && extra_st > 0) {                      // every thread checks the chunk's state patches against its four arcs
+                const int s_lo = i_lo > extra_pi ? i_lo : extra_pi;
+                for (int i = s_lo; i < i_hi; ++i) {
+                    const int rel = i - i_lo;
+                    const uint32_t *q = lm + (1 + rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
+                    const int a = (int)q[0] - p.base - my_i0;
+                    if ((unsigned)a < 4u) mine.st4 = (mine.st4 & ~(0xFFu << (8 * a))) | ((q[1] & 0xFFu) << (8 * a));
+                }
             }
             __syncthreads();                               // the chunk has been consumed before the next one lands in lm
         }
@@ -438,25 +542,32 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
             __syncthreads();
         }
         // ---- scan
-        Key best;
-        best.c = 0;
-        best.r = kNone;
-        best.p = kNone;
-        if (REG) {
-            eval_tile<T, RULE, OPT>(mine, pi_view, p.base + my_i0, p.m_s, next_arc, p.block_size, rstar, best);
+        if (CAND) {
+            int64_t c1, c2;
+            uint32_t p1, p2;
+            eval_tile_best2<T>(mine, pi_view, p.base + my_i0, c1, p1, c2, p2);
+            publish_candidates(c1, p1, c2, p2, p.slots, seq);
         } else {
-            for (int i0 = my_i0; i0 < p.count_padded; i0 += gridDim.x * kResidentTile) {
-                TileData<T> d;
-                load_tile<T>(p.src, p.tgt, p.cost, p.state, i0, d);
-                eval_tile<T, RULE, OPT>(d, pi_view, p.base + i0, p.m_s, next_arc, p.block_size, rstar, best);
+            Key best;
+            best.c = 0;
+            best.r = kNone;
+            best.p = kNone;
+            if (REG) {
+                eval_tile<T, RULE, OPT>(mine, pi_view, p.base + my_i0, p.m_s, next_arc, p.block_size, rstar, best);
+            } else {
+                for (int i0 = my_i0; i0 < p.count_padded; i0 += gridDim.x * kResidentTile) {
+                    TileData<T> d;
+                    load_tile<T>(p.src, p.tgt, p.cost, p.state, i0, d);
+                    eval_tile<T, RULE, OPT>(d, pi_view, p.base + i0, p.m_s, next_arc, p.block_size, rstar, best);
+                }
             }
+            publish_best<RULE, true, kResidentThreads>(best, p.slots + blockIdx.x, seq);
         }
-        publish_best<RULE, true, kResidentThreads>(best, p.slots + blockIdx.x, seq);
         last = seq;
         served += 1;
         idle_since = __builtin_amdgcn_s_memrealtime();
         scan_ticks += idle_since - t_seen;
-        __syncthreads();                                   // lm and wave_best are reused by the next request
+        __syncthreads();                                   // lm and the reduction scratch are reused by the next request
     }
 }
 
@@ -575,7 +686,25 @@ struct mcf_engine {
     // resident mode (flag MCF_ENGINE_RESIDENT): mailbox in BAR-mapped fine-grained VRAM, exit record in pinned host memory
     bool resident_ok = false, resident_running = false, resident_reg = false;
     uint32_t *mailbox = nullptr;
-    int mailbox_lines = 0;
+    int mailbox_lines = 0, mailbox_max_st = 0;
+    uint32_t prev_seq = 0;
+    // candidate cache (flag MCF_ENGINE_CANDIDATES; Best Eligible, resident, register-resident tiles): see cand_* below
+    bool cand_on = false, cand_valid = false;
+    std::vector<int32_t> h_src, h_tgt;            // host mirrors of the resident arrays (search arcs only)
+    std::vector<int64_t> h_cost;
+    std::vector<int8_t> h_state;
+    std::vector<int32_t> adj_start, adj_arc;      // arcs incident to each node
+    std::vector<uint32_t> node_mark, arc_mark;    // == cand_epoch: touched since the last device search
+    uint32_t cand_epoch = 1;
+    std::vector<int32_t> dirty_nodes, dirty_arcs;
+    std::vector<int64_t> dirty_vals;              // current potential of dirty_nodes[i]
+    std::vector<int32_t> node_slot;               // position of a marked node in dirty_nodes
+    bool dirty_overflow = false;                  // too much is dirty for the host to answer: only collect patches until the device searches
+    int64_t dirty_degree = 0;
+    struct CandKey { int64_t c; uint32_t p; };
+    std::vector<CandKey> cand_list;               // sorted; complete below cand_thr
+    size_t cand_ptr = 0;
+    CandKey cand_thr{0, 0xFFFFFFFFu};             // p == kNone: the list holds every eligible arc
     uint32_t *h_exit = nullptr, *d_exit = nullptr;
     int res_grid = 0;
     hipEvent_t res_start = nullptr, res_stop = nullptr;
@@ -695,8 +824,19 @@ int launch_scan(mcf_engine *e, bool with_patches, bool timed)
 }
 
 // ship the pending patches with update_kernel (lists too long for the kernel arguments, or explicit flush)
+void cand_reset_dirty(mcf_engine *e);
 int flush_pending(mcf_engine *e)
 {
+    if (e->cand_on && (!e->dirty_nodes.empty() || !e->dirty_arcs.empty())) {
+        // candidate mode keeps its pending patches as "dirty" sets: turn them into lists (current values from the mirrors)
+        e->pend_node.swap(e->dirty_nodes);
+        e->pend_val.swap(e->dirty_vals);
+        e->pend_arc.assign(e->dirty_arcs.begin(), e->dirty_arcs.end());
+        e->pend_state.resize(e->pend_arc.size());
+        for (size_t i = 0; i < e->pend_arc.size(); ++i) e->pend_state[i] = e->h_state[e->pend_arc[i]];
+        cand_reset_dirty(e);
+        e->cand_valid = false;
+    }
     const int n_pi = (int)e->pend_node.size(), n_st = (int)e->pend_arc.size();
     if (n_pi == 0 && n_st == 0) return MCF_OK;
     mcf_engine::Staging &s = e->stage[e->stage_next];
@@ -782,10 +922,14 @@ void launch_resident_r(mcf_engine *e, const ResidentParams<T> &p)
 {
     const dim3 grid(e->res_grid), block(kResidentThreads);
     const bool lpi = e->lds_pi;
-    if (e->resident_reg && lpi) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
-    else if (e->resident_reg) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
-    else if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
-    else hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    if (e->cand_on) {     // candidates: Best Eligible, register-resident tiles only
+        if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, true, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+        else hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, false, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    }
+    else if (e->resident_reg && lpi) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, true, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    else if (e->resident_reg) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, false, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    else if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, true, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    else hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, false, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
 }
 
 template <typename T>
@@ -795,7 +939,7 @@ int launch_resident(mcf_engine *e, uint32_t start_seq)
     p.src = e->d_src; p.tgt = e->d_tgt; p.cost = (const T *)e->d_cost; p.state = e->d_state; p.pi = (T *)e->d_pi;
     p.slots = e->d_slots; p.mailbox = e->mailbox; p.exit_word = e->d_exit;
     p.base = e->begin; p.count_padded = e->count_padded; p.m_s = e->d.search_arc_num; p.block_size = e->block_size;
-    p.start_seq = start_seq; p.idle_ticks = kResidentIdleTicks; p.max_pi = e->d.node_count;
+    p.start_seq = start_seq; p.idle_ticks = kResidentIdleTicks; p.max_pi = e->d.node_count; p.max_st = e->mailbox_max_st;
     const bool opt = e->d.semantics == MCF_SEM_OPTIMIZED;
     switch (e->d.rule) {
     case MCF_RULE_BEST_ELIGIBLE: launch_resident_r<T, MCF_RULE_BEST_ELIGIBLE, false>(e, p); break;
@@ -834,13 +978,21 @@ void resident_post(mcf_engine *e, uint32_t seq, uint32_t cmd, bool with_patches)
 {
     alignas(16) uint32_t line[16];
     const int n_pi = with_patches ? (int)e->pend_node.size() : 0, n_st = with_patches ? (int)e->pend_arc.size() : 0;
-    for (int l = 0, i = 1; i < n_pi; ++l) {                 // patches 1.. go to lines 1..; patch 0 rides in the header
+    // entries beyond the header: potential patches 1.., then state patches 2..
+    const int extra_pi = n_pi > 1 ? n_pi - 1 : 0, extra_st = n_st > 2 ? n_st - 2 : 0, entries = extra_pi + extra_st;
+    for (int l = 0, i = 0; i < entries; ++l) {
         memset(line, 0, sizeof(line));
-        for (int k = 0; k < kMailboxPatchesPerLine && i < n_pi; ++k, ++i) {
-            const uint64_t v = (uint64_t)e->pend_val[i];
-            line[3 * k] = (uint32_t)e->pend_node[i];
-            line[3 * k + 1] = (uint32_t)v;
-            line[3 * k + 2] = (uint32_t)(v >> 32);
+        for (int k = 0; k < kMailboxPatchesPerLine && i < entries; ++k, ++i) {
+            if (i < extra_pi) {
+                const uint64_t v = (uint64_t)e->pend_val[i + 1];
+                line[3 * k] = (uint32_t)e->pend_node[i + 1];
+                line[3 * k + 1] = (uint32_t)v;
+                line[3 * k + 2] = (uint32_t)(v >> 32);
+            } else {
+                const int j = i - extra_pi + 2;
+                line[3 * k] = (uint32_t)e->pend_arc[j];
+                line[3 * k + 1] = (uint32_t)e->pend_state[j];
+            }
         }
         line[15] = seq;
         mailbox_write_line(e->mailbox + 16 * (size_t)(l + 1), line);
@@ -858,7 +1010,7 @@ void resident_post(mcf_engine *e, uint32_t seq, uint32_t cmd, bool with_patches)
     line[3] = (uint32_t)rstar;
     line[4] = (uint32_t)n_pi;
     line[5] = (uint32_t)n_st;
-    for (int k = 0; k < n_st; ++k) { line[6 + 2 * k] = (uint32_t)e->pend_arc[k]; line[7 + 2 * k] = (uint32_t)e->pend_state[k]; }
+    for (int k = 0; k < n_st && k < 2; ++k) { line[6 + 2 * k] = (uint32_t)e->pend_arc[k]; line[7 + 2 * k] = (uint32_t)e->pend_state[k]; }
     if (n_pi > 0) {
         const uint64_t v = (uint64_t)e->pend_val[0];
         line[10] = (uint32_t)e->pend_node[0];
@@ -866,7 +1018,7 @@ void resident_post(mcf_engine *e, uint32_t seq, uint32_t cmd, bool with_patches)
         line[12] = (uint32_t)(v >> 32);
     }
     line[15] = seq;
-    if (n_pi > 1) _mm_sfence();                     // patch lines leave the write-combining buffers before the header does
+    if (entries > 0) _mm_sfence();                  // entry lines leave the write-combining buffers before the header does
     mailbox_write_line(e->mailbox, line);
     _mm_sfence();
 }
@@ -874,6 +1026,7 @@ void resident_post(mcf_engine *e, uint32_t seq, uint32_t cmd, bool with_patches)
 int resident_stop(mcf_engine *e)
 {
     if (!e->resident_running) return MCF_OK;
+    e->prev_seq = e->seq;
     e->seq += 1;
     if (e->seq == 0) e->seq = 1;
     resident_post(e, e->seq, 1u, false);
@@ -910,7 +1063,7 @@ int collect(mcf_engine *e, int grid, Key *out)
                 // find the request in the mailbox (start_seq = the previous request)
                 HIP_TRY(hipStreamSynchronize(e->stream));
                 e->resident_running = false;
-                int rc = resident_start(e, seq - 1 == 0 ? 0xFFFFFFFFu : seq - 1);
+                int rc = resident_start(e, e->prev_seq);
                 if (rc) return rc;
             }
             if ((++spins & 0xFFFFF) == 0) {
@@ -941,24 +1094,196 @@ int collect(mcf_engine *e, int grid, Key *out)
     return MCF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ candidate cache
+// Best Eligible picks argmin (c, arc) over ALL search arcs with the CURRENT potentials (NS.cs:1644-1667).  A pivot changes the
+// potentials of one subtree and one or two states, so only arcs that touch those nodes ("dirty" arcs) change their key; every other
+// arc keeps the key the last device search saw.  That search returned a sorted candidate list that is COMPLETE below a threshold
+// (every eligible arc with a smaller key is on it).  Hence, exactly:
+//     min over clean arcs = first list entry that is still clean          (if there is one: all unlisted clean arcs lie above the threshold)
+//     min over dirty arcs = evaluated here from the host mirrors           (a handful of arcs: adjacency of the moved nodes)
+// and the entering arc is the smaller of the two.  When the list has run out and the best dirty key is not below the threshold,
+// or too many nodes are dirty, the device searches again.  The pivot sequence is the reference's, arc for arc (tests: every
+// parity test runs with the cache on and off); the device still does every full scan.
+constexpr int kCandMaxDirtyNodes = 96;          // beyond this the host evaluation costs more than a device search
+constexpr int64_t kCandMaxDirtyDegree = 1536;
+constexpr int kCandMaxDirtyArcs = 256;
+constexpr int kCandMaxAvgDegree = 24;           // denser graphs: a single moved node already touches too many arcs
+
+inline bool cand_key_less(const mcf_engine::CandKey &a, const mcf_engine::CandKey &b) { return a.c < b.c || (a.c == b.c && a.p < b.p); }
+
+inline void cand_touch_node(mcf_engine *e, int u, int64_t value)
+{
+    if (e->node_mark[u] == e->cand_epoch) { e->dirty_vals[e->node_slot[u]] = value; return; }
+    e->node_mark[u] = e->cand_epoch;
+    e->node_slot[u] = (int32_t)e->dirty_nodes.size();
+    e->dirty_nodes.push_back(u);
+    e->dirty_vals.push_back(value);
+    if (!e->dirty_overflow) e->dirty_degree += e->adj_start[u + 1] - e->adj_start[u];
+}
+// a list the host will not evaluate anyway: just remember the patches (a repeated node is harmless, the later entry carries the later value
+// and the kernel applies entries in list order within a thread -- but two threads may race, so repeated nodes are de-duplicated at post time)
+inline void cand_note_overflow(mcf_engine *e) { e->dirty_overflow = true; }
+void cand_touch_arc(mcf_engine *e, int a)
+{
+    if (e->arc_mark[a] == e->cand_epoch) return;
+    e->arc_mark[a] = e->cand_epoch;
+    e->dirty_arcs.push_back(a);
+}
+inline bool cand_arc_dirty(const mcf_engine *e, int a)
+{
+    return e->arc_mark[a] == e->cand_epoch || e->node_mark[e->h_src[a]] == e->cand_epoch || e->node_mark[e->h_tgt[a]] == e->cand_epoch;
+}
+inline void cand_eval(const mcf_engine *e, int a, mcf_engine::CandKey &best)
+{
+    const int st = e->h_state[a];
+    if (st == 0) return;
+    const int64_t d = e->h_cost[a] + e->pi[e->h_src[a]] - e->pi[e->h_tgt[a]];
+    const int64_t rc = st > 0 ? d : -d;
+    if (rc >= 0) return;
+    const mcf_engine::CandKey k{rc, (uint32_t)a};
+    if (best.p == kNone || cand_key_less(k, best)) best = k;
+}
+
+// true: *k holds the entering arc (or "none": the scan would find nothing either) without asking the device
+bool cand_try_host(mcf_engine *e, Key *k)
+{
+    if (!e->cand_valid || e->dirty_overflow) return false;
+    if ((int)e->dirty_nodes.size() > kCandMaxDirtyNodes || e->dirty_degree > kCandMaxDirtyDegree || (int)e->dirty_arcs.size() > kCandMaxDirtyArcs) return false;
+    mcf_engine::CandKey best_d{0, kNone};
+    for (int a : e->dirty_arcs) cand_eval(e, a, best_d);
+    for (int u : e->dirty_nodes)
+        for (int i = e->adj_start[u]; i < e->adj_start[u + 1]; ++i) cand_eval(e, e->adj_arc[i], best_d);
+    while (e->cand_ptr < e->cand_list.size() && cand_arc_dirty(e, (int)e->cand_list[e->cand_ptr].p)) e->cand_ptr++;
+    mcf_engine::CandKey win{0, kNone};
+    if (e->cand_ptr < e->cand_list.size()) {
+        win = e->cand_list[e->cand_ptr];
+        if (best_d.p != kNone && cand_key_less(best_d, win)) win = best_d;
+    } else if (e->cand_thr.p == kNone) {
+        win = best_d;                                   // the list was complete: nothing clean is left
+    } else if (best_d.p != kNone && cand_key_less(best_d, e->cand_thr)) {
+        win = best_d;                                   // everything clean and unlisted lies above the threshold
+    } else {
+        return false;
+    }
+    k->c = win.p == kNone ? 0 : win.c;
+    k->r = 0;
+    k->p = win.p;
+    return true;
+}
+
+// wait for the candidate records of request `seq` and rebuild the list
+int cand_collect(mcf_engine *e, Key *out)
+{
+    const double t0 = mcf::now_ns();
+    const volatile Slot *slots = e->h_slots;
+    const uint32_t seq = e->seq;
+    e->cand_list.clear();
+    e->cand_thr = mcf_engine::CandKey{0, kNone};
+    for (int g = 0; g < e->res_grid; ++g) {
+        const volatile Slot *rec = slots + (size_t)g * kCandRecords;
+        uint64_t spins = 0;
+        for (;;) {
+            bool all = true;
+            for (int r = 0; r <= kCandPerGroup; ++r) all = all && rec[r].tag == seq;
+            if (all) break;
+            _mm_pause();
+            if (e->resident_running && (spins & 0xFFF) == 0xFFF && ((const volatile uint32_t *)e->h_exit)[0] != 0) {
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                e->resident_running = false;
+                int rc = resident_start(e, e->prev_seq);
+                if (rc) return rc;
+            }
+            if ((++spins & 0xFFFFF) == 0) {
+                const hipError_t q = hipStreamQuery(e->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return mcf::fail(MCF_ERR_HIP, "resident grid failed: %s", hipGetErrorString(q));
+                if (mcf::now_ns() - t0 > 20e9) return mcf::fail(MCF_ERR_TIMEOUT, "no answer from the device after 20 s (workgroup %d of %d)", g, e->res_grid);
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (int r = 0; r < kCandPerGroup; ++r)
+            if (rec[r].p != kNone) e->cand_list.push_back(mcf_engine::CandKey{rec[r].c, rec[r].p});
+        if (rec[kCandPerGroup].p != kNone) {
+            const mcf_engine::CandKey t{rec[kCandPerGroup].c, rec[kCandPerGroup].p};
+            if (e->cand_thr.p == kNone || cand_key_less(t, e->cand_thr)) e->cand_thr = t;
+        }
+    }
+    e->st.host_wait_ns += mcf::now_ns() - t0;
+    if (e->cand_thr.p != kNone) {      // keep only what is provably complete: keys below the smallest unreported key
+        size_t keep = 0;
+        for (size_t i = 0; i < e->cand_list.size(); ++i)
+            if (cand_key_less(e->cand_list[i], e->cand_thr)) e->cand_list[keep++] = e->cand_list[i];
+        e->cand_list.resize(keep);
+    }
+    std::sort(e->cand_list.begin(), e->cand_list.end(), cand_key_less);
+    e->cand_ptr = 0;
+    e->cand_valid = true;
+    out->r = 0;
+    if (e->cand_list.empty()) { out->c = 0; out->p = kNone; }
+    else { out->c = e->cand_list[0].c; out->p = e->cand_list[0].p; }
+    return MCF_OK;
+}
+
+// new epoch: nothing is dirty any more (the device has seen every patch)
+void cand_reset_dirty(mcf_engine *e)
+{
+    e->dirty_nodes.clear();
+    e->dirty_vals.clear();
+    e->dirty_arcs.clear();
+    e->dirty_degree = 0;
+    e->dirty_overflow = false;
+    if (++e->cand_epoch == 0) {
+        std::fill(e->node_mark.begin(), e->node_mark.end(), 0u);
+        std::fill(e->arc_mark.begin(), e->arc_mark.end(), 0u);
+        e->cand_epoch = 1;
+    }
+}
+
 int local_search(mcf_engine *e, Key *k)
 {
     if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
     const double t0 = mcf::now_ns();
     const bool had = !e->pend_node.empty() || !e->pend_arc.empty();
+    if (e->cand_on) {
+        // ---- candidate cache: answer from the host when that is provably the scan's answer
+        if (cand_try_host(e, k)) { e->st.searches += 1; e->st.host_decided += 1; return MCF_OK; }
+        // the device searches: ship every node / arc touched since its last search, with their current values
+        e->pend_node.swap(e->dirty_nodes);
+        e->pend_val.swap(e->dirty_vals);
+        e->pend_arc.assign(e->dirty_arcs.begin(), e->dirty_arcs.end());
+        e->pend_state.resize(e->pend_arc.size());
+        for (size_t i = 0; i < e->pend_arc.size(); ++i) e->pend_state[i] = e->h_state[e->pend_arc[i]];
+        if ((int)e->pend_arc.size() > e->mailbox_max_st) {      // cannot happen with kCandMaxDirtyArcs, kept for safety
+            int rc = resident_stop(e);
+            if (!rc) rc = flush_pending(e);
+            if (rc) return rc;
+        }
+        e->prev_seq = e->seq;
+        e->seq += 1;
+        if (e->seq == 0) e->seq = 1;
+        int rc = resident_start(e, e->prev_seq);
+        if (rc) return rc;
+        resident_post(e, e->seq, 0u, true);
+        if (had || !e->pend_node.empty()) e->st.inline_updates += 1;
+        e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
+        cand_reset_dirty(e);
+        e->st.host_launch_ns += mcf::now_ns() - t0;
+        e->st.searches += 1;
+        e->st.arcs_scanned += e->end - e->begin;
+        return cand_collect(e, k);
+    }
     if (e->resident_ok) {
         // ---- resident mode: post the request into the mailbox, the grid is already running
-        const bool fits = (int)e->pend_arc.size() <= kResidentMaxState;     // any number of potentials fits the mailbox
+        const bool fits = (int)e->pend_arc.size() <= e->mailbox_max_st;     // any number of potentials fits the mailbox
         if (!fits) {
             // a list that does not fit the mailbox: stop the grid, ship it with update_kernel, start again
             int rc = resident_stop(e);
             if (!rc) rc = flush_pending(e);
             if (rc) return rc;
         }
-        const uint32_t prev = e->seq;
+        e->prev_seq = e->seq;
         e->seq += 1;
         if (e->seq == 0) e->seq = 1;
-        int rc = resident_start(e, prev);
+        int rc = resident_start(e, e->prev_seq);
         if (rc) return rc;
         resident_post(e, e->seq, 0u, fits);
         if (fits) {
@@ -1128,8 +1453,8 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         s.cap_nodes = desc->node_count;
         chk(hipHostMalloc((void **)&s.nodes, sizeof(int32_t) * s.cap_nodes, hipHostMallocMapped | hipHostMallocCoherent));
         chk(hipHostMalloc((void **)&s.values, sizeof(int64_t) * s.cap_nodes, hipHostMallocMapped | hipHostMallocCoherent));
-        chk(hipHostMalloc((void **)&s.arcs, sizeof(int32_t) * 64, hipHostMallocMapped | hipHostMallocCoherent));
-        chk(hipHostMalloc((void **)&s.states, sizeof(int32_t) * 64, hipHostMallocMapped | hipHostMallocCoherent));
+        chk(hipHostMalloc((void **)&s.arcs, sizeof(int32_t) * 4096, hipHostMallocMapped | hipHostMallocCoherent));
+        chk(hipHostMalloc((void **)&s.states, sizeof(int32_t) * 4096, hipHostMallocMapped | hipHostMallocCoherent));
         if (err == hipSuccess) {
             chk(hipHostGetDevicePointer(&s.d_nodes, s.nodes, 0));
             chk(hipHostGetDevicePointer(&s.d_values, s.values, 0));
@@ -1152,7 +1477,8 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         if (env && env[0] == '0') want = false;
         const bool whole = e->begin == 0 && e->end == desc->search_arc_num;
         if (want && whole && !(desc->flags & (MCF_ENGINE_TIME_EVERY_KERNEL | MCF_ENGINE_NO_INLINE_UPDATE))) {
-            e->mailbox_lines = 2 + (desc->node_count + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
+            e->mailbox_max_st = 4096;
+            e->mailbox_lines = 2 + (desc->node_count + e->mailbox_max_st + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
             e->mailbox = alloc_bar_vram(desc->device, (size_t)e->mailbox_lines * 64);
             if (e->mailbox && hipHostMalloc((void **)&e->h_exit, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
                 hipHostGetDevicePointer((void **)&e->d_exit, e->h_exit, 0) == hipSuccess &&
@@ -1164,12 +1490,15 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
                 e->resident_reg = tiles <= kResidentMaxGrid;
                 e->res_grid = e->resident_reg ? tiles : kResidentMaxGrid;
                 e->resident_ok = true;
+                e->cand_on = (desc->flags & MCF_ENGINE_CANDIDATES) && e->resident_reg && desc->rule == MCF_RULE_BEST_ELIGIBLE &&
+                             2 * (int64_t)desc->search_arc_num <= (int64_t)kCandMaxAvgDegree * desc->node_count;
             }
         }
     }
     e->st.scan_workgroups = e->resident_ok ? e->res_grid : e->grid;
     e->st.scan_threads = (e->resident_ok || e->lds_pi) ? kResidentThreads : kThreads;
     e->st.resident = e->resident_ok ? 1 : 0;
+    e->st.candidates = e->cand_on ? 1 : 0;
     e->st.bytes_per_scan = (int64_t)(desc->int_width == 64 ? 17 : 13) * count + (int64_t)w * desc->node_count;
     *out = e;
     return MCF_OK;
@@ -1247,6 +1576,28 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
     }
     e->pi.assign(pi, pi + n);
     e->mirror_valid = true;
+    if (e->cand_on) {
+        const int m_s = e->d.search_arc_num;
+        e->h_src.assign(source, source + m_s);
+        e->h_tgt.assign(target, target + m_s);
+        e->h_cost.assign(cost, cost + m_s);
+        e->h_state.assign(state, state + m_s);
+        e->adj_start.assign(n + 1, 0);
+        for (int a = 0; a < m_s; ++a) { e->adj_start[source[a] + 1]++; if (target[a] != source[a]) e->adj_start[target[a] + 1]++; }
+        for (int u = 0; u < n; ++u) e->adj_start[u + 1] += e->adj_start[u];
+        e->adj_arc.assign(e->adj_start[n], 0);
+        std::vector<int32_t> fill(e->adj_start.begin(), e->adj_start.end() - 1);
+        for (int a = 0; a < m_s; ++a) { e->adj_arc[fill[source[a]]++] = a; if (target[a] != source[a]) e->adj_arc[fill[target[a]]++] = a; }
+        e->node_mark.assign(n, 0u);
+        e->node_slot.assign(n, 0);
+        e->dirty_vals.clear();
+        e->dirty_overflow = false;
+        e->arc_mark.assign(m_s, 0u);
+        e->cand_epoch = 1;
+        e->dirty_nodes.clear(); e->dirty_arcs.clear(); e->dirty_degree = 0;
+        e->cand_valid = false;
+        e->cand_list.clear();
+    }
     e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
     e->next_arc = 0;
     e->uploaded = true;
@@ -1260,6 +1611,7 @@ int mcf_engine_patch_state(mcf_engine *e, int32_t count, const int32_t *arcs, co
         if (arcs[i] < 0 || arcs[i] >= e->d.arc_capacity) return mcf::fail(MCF_ERR_INVALID, "arc %d out of range", arcs[i]);
         if (states[i] < -1 || states[i] > 1) return mcf::fail(MCF_ERR_INVALID, "state %d is not -1/0/1", states[i]);
         if (arcs[i] < e->begin || arcs[i] >= e->end) continue;   // not resident here (outside the search range or another shard)
+        if (e->cand_on) { e->h_state[arcs[i]] = states[i]; cand_touch_arc(e, arcs[i]); continue; }
         bool dup = false;
         for (size_t j = 0; j < e->pend_arc.size(); ++j)
             if (e->pend_arc[j] == arcs[i]) { e->pend_state[j] = states[i]; dup = true; }
@@ -1280,6 +1632,16 @@ int mcf_engine_update_potential(mcf_engine *e, int32_t count, const int32_t *nod
         int rc = mcf_engine_download_pi(e, e->pi.data());
         if (rc) return rc;
         e->mirror_valid = true;
+    }
+    if (e->cand_on) {
+        for (int i = 0; i < count; ++i) {
+            if ((unsigned)nodes[i] >= (unsigned)e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "node %d out of range", nodes[i]);
+            if (e->d.int_width == 32 && !fits32(e->pi[nodes[i]] + sigma)) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d leaves int32; create the engine with int_width 64", nodes[i]);
+        }
+        if (count > kCandMaxDirtyNodes) cand_note_overflow(e);
+        for (int i = 0; i < count; ++i) { const int64_t v = (e->pi[nodes[i]] += sigma); cand_touch_node(e, nodes[i], v); }
+        e->st.potential_nodes += count;
+        return MCF_OK;
     }
     // one list per dispatch: a second list may repeat nodes of the first
     if (!e->pend_node.empty()) { int rc = resident_stop(e); if (!rc) rc = flush_pending(e); if (rc) return rc; }
@@ -1304,13 +1666,19 @@ int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes,
     if (!e || count < 0 || (count && (!nodes || !values))) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_set_potential: bad arguments");
     if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
     if (count == 0) return MCF_OK;
-    if (!e->pend_node.empty()) { int rc = resident_stop(e); if (!rc) rc = flush_pending(e); if (rc) return rc; }
     if (count > e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "%d nodes in a graph of %d", count, e->d.node_count);
     const bool narrow = e->d.int_width == 32;
     for (int i = 0; i < count; ++i) {
         if ((unsigned)nodes[i] >= (unsigned)e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "node %d out of range", nodes[i]);
         if (narrow && !fits32(values[i])) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d leaves int32; create the engine with int_width 64", nodes[i]);
     }
+    if (e->cand_on) {                 // the mirror stays authoritative in candidate mode
+        if (count > kCandMaxDirtyNodes) cand_note_overflow(e);
+        for (int i = 0; i < count; ++i) { e->pi[nodes[i]] = values[i]; cand_touch_node(e, nodes[i], values[i]); }
+        e->st.potential_nodes += count;
+        return MCF_OK;
+    }
+    if (!e->pend_node.empty()) { int rc = resident_stop(e); if (!rc) rc = flush_pending(e); if (rc) return rc; }
     e->pend_node.assign(nodes, nodes + count);
     e->pend_val.assign(values, values + count);
     e->mirror_valid = false;
@@ -1332,6 +1700,7 @@ int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, con
         if ((unsigned)source[i] >= (unsigned)e->d.node_count || (unsigned)target[i] >= (unsigned)e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "arc %d: end point out of range", a);
         if (a < e->begin || a >= e->end) continue;
         const int l = a - e->begin;
+        if (e->cand_on) return mcf::fail(MCF_ERR_STATE, "mcf_engine_patch_arcs is not available with MCF_ENGINE_CANDIDATES (upload again)");
         HIP_TRY(hipMemcpy(e->d_src + l, &source[i], 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(e->d_tgt + l, &target[i], 4, hipMemcpyHostToDevice));
         if (e->d.int_width == 32) {
@@ -1461,6 +1830,7 @@ int mcf_engine_reset_stats(mcf_engine *e)
     e->st.scan_threads = keep.scan_threads;
     e->st.bytes_per_scan = keep.bytes_per_scan;
     e->st.resident = keep.resident;
+    e->st.candidates = keep.candidates;
     return MCF_OK;
 }
 

@@ -30,7 +30,7 @@ def _oracle_scan(rule, optimized, a, m_s, block, next_arc):
     return O.scan_block(m_s, a["state"], a["cost"], a["src"], a["tgt"], a["pi"], block, optimized, next_arc)
 
 
-MODES = [pytest.param(0, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch")]
+MODES = [pytest.param(0, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"), pytest.param(M.ENGINE_CANDIDATES, id="candidates")]
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -75,9 +75,11 @@ def test_scan_matches_oracle_on_random_arrays(width, rule, optimized, mode):
         assert np.array_equal(eng.download_pi(), a["pi"])
         assert np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
         st = eng.stats()
-        assert st["searches"] == 12 and st["resident"] == (0 if mode else 1)
-        if mode:
+        assert st["searches"] == 12 and st["resident"] == (0 if mode == M.ENGINE_DISPATCH else 1)
+        if mode == M.ENGINE_DISPATCH:
             assert (st["inline_updates"] > 0 and st["update_launches"] > 0) or n < 97
+        elif mode == M.ENGINE_CANDIDATES and rule == O.RULE_BEST and m_s <= 1 << 20 and 2 * m_s <= 24 * n:
+            assert st["candidates"] == 1 and st["resident_requests"] + st["host_decided"] >= 12
         else:
             assert st["resident_requests"] >= 12 and st["update_launches"] <= 1    # the patches queued after the last search
 
@@ -146,7 +148,9 @@ def test_solve_is_pivot_for_pivot_identical(name, mode):
         assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
         m = ns.get_metrics()
         assert m["iterations"] == o.n_pivots and m["block_size"] == o.block_size and m["search_arc_num"] == o.search_arc_num
-        assert m["engine"]["resident"] == (0 if mode else 1)
+        assert m["engine"]["resident"] == (0 if mode == M.ENGINE_DISPATCH else 1)
+        if mode == M.ENGINE_CANDIDATES and rule == O.RULE_BEST and 2 * o.search_arc_num <= 24 * (p.n + 1):
+            assert m["engine"]["candidates"] == 1 and m["engine"]["host_decided"] + m["engine"]["resident_requests"] >= o.n_pivots
 
 
 @pytest.mark.parametrize("name,path,want", fixtures(), ids=[f[0] for f in fixtures()])
@@ -323,6 +327,41 @@ def test_full_size_configs_certified_optimal():
         assert o.solve()[0] == O.OPTIMAL and o.total_cost == cost, name
         m = ns.get_metrics()
         assert m["int_width"] == width and m["iterations"] > 0
+
+
+def test_candidate_cache_answers_most_searches_and_changes_nothing():
+    """MCF_ENGINE_CANDIDATES on a mid-size NETGEN-like solve: identical pivot sequence, most searches answered without a
+    device request."""
+    g = M.netgen_like(13502460, 20_000, 70_000, 140, 140)
+    p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
+    o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, O.RULE_BEST, flags=M.ENGINE_CANDIDATES)
+    assert st == st_o == 1 and np.array_equal(ns.trace(), tr_o)
+    assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
+    e = ns.get_metrics()["engine"]
+    assert e["candidates"] == 1 and e["host_decided"] > 2 * e["resident_requests"], e
+    # potential updates given as += sigma (the C# host's call) keep the cache consistent too
+    rng = np.random.default_rng(11)
+    m_s, n = 50_000, 9_000
+    a = _random_soa(rng, m_s, n, 40, 400, extra=0)
+    eng = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible, flags=M.ENGINE_CANDIDATES)
+    eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+    for it in range(300):
+        f, e_, c = eng.find_entering()
+        assert (f, e_, c) == O.scan_best(m_s, a["state"], a["cost"], a["src"], a["tgt"], a["pi"]), it
+        if not f:
+            break
+        a["state"][e_] = 0
+        eng.patch_state([e_], [0])
+        nodes = rng.choice(n, size=int(rng.choice([1, 1, 2, 3, 30, 700])), replace=False).astype(np.int32)
+        sigma = int(rng.integers(-5, 6))
+        a["pi"][nodes] += sigma
+        if it % 2:
+            eng.update_potential(nodes, sigma)
+        else:
+            eng.set_potential(nodes, a["pi"][nodes])
+    st2 = eng.stats()
+    assert st2["host_decided"] > 50 and st2["resident_requests"] > 5, st2
+    assert np.array_equal(eng.download_pi(), a["pi"]) and np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
 
 
 def test_sigma_and_value_updates_can_be_mixed():

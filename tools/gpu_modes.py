@@ -9,7 +9,7 @@ cases = (("config2_block_i32", M.netgen_like(13502460, 10_000, 30_000, 100, 100)
          ("config4_best", M.assignment(42, 1000, 1, 100), M.PivotRule.BestEligible))
 out = {}
 for name, g, rule in cases:
-    for mode, flags in (("dispatch", M.ENGINE_SAMPLE_KERNEL_TIME | M.ENGINE_DISPATCH), ("resident", M.ENGINE_RESIDENT)):
+    for mode, flags in (("dispatch", M.ENGINE_SAMPLE_KERNEL_TIME | M.ENGINE_DISPATCH), ("resident", M.ENGINE_RESIDENT), ("candidates", M.ENGINE_CANDIDATES)):
         ns = M.NetworkSimplex.from_problem(g).set_pivot_rule(rule).enable_optimized_pivot(True).set_device(0, 0, 0, flags)
         ns.prepare()
         if name.startswith("netgen_1M"):
@@ -27,7 +27,7 @@ for name, g, rule in cases:
                  post_or_launch_us=e["host_launch_ns"] / max(e["searches"], 1) / 1e3, inline=e["inline_updates"], staged=e["update_launches"],
                  grid=e["scan_workgroups"], resident=e["resident"], resident_launches=e["resident_launches"],
                  resident_requests=e["resident_requests"], in_kernel_scan_us=e["resident_scan_ns"] / max(e["resident_requests"], 1) / 1e3,
-                 kernel_us=e["timed_scan_ns"] / max(e["timed_scans"], 1) / 1e3, avg_subtree=m["potential_nodes"] / it)
+                 kernel_us=e["timed_scan_ns"] / max(e["timed_scans"], 1) / 1e3, host_decided=e["host_decided"], avg_subtree=m["potential_nodes"] / it)
         out[f"{name}/{mode}"] = r
         print(name, mode, json.dumps(r), flush=True)
         del ns
