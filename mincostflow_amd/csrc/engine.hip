@@ -211,8 +211,8 @@ __device__ __forceinline__ void publish_best(Key best, Slot *slot, uint32_t tag)
     __syncthreads();
     if (tid == 0) {
         Key k = wave_best[0];
-#pragma unroll
-        for (int w = 1; w < NT / 64; ++w) take_if_better<RULE>(k, wave_best[w].c, wave_best[w].r, wave_best[w].p);
+        const int waves = (int)(blockDim.x >> 6);          // NT is the largest block the kernel is launched with
+        for (int w = 1; w < waves; ++w) take_if_better<RULE>(k, wave_best[w].c, wave_best[w].r, wave_best[w].p);
         typedef uint32_t v4u __attribute__((ext_vector_type(4)));
         v4u out;
         out.x = (uint32_t)(uint64_t)k.c;
@@ -296,8 +296,6 @@ __global__ __launch_bounds__(kResidentThreads) void scan_kernel_lds(const ScanPa
 //
 constexpr int kMailboxLines = 256;                // lines staged in LDS at a time: 16 KB = line 0 + a chunk of 255 patch lines (1275 patches)
 constexpr int kMailboxPatchesPerLine = 5;
-constexpr int kChunkLines = kMailboxLines - 1;
-constexpr int kResidentMaxState = 2;
 
 template <typename T>
 struct ResidentParams {
@@ -407,7 +405,8 @@ __device__ __forceinline__ void publish_candidates(int64_t c1, uint32_t p1, int6
         for (int k = 0; k < kCandPerGroup; ++k) { kc[k] = 0; kp[k] = kNone; }
         int64_t tc = 0;
         uint32_t tp = kNone;                                 // threshold
-        for (int w = 0; w < kResidentThreads / 64; ++w) {
+        const int waves = (int)(blockDim.x >> 6);
+        for (int w = 0; w < waves; ++w) {
             int64_t c = wave_first[w].c;
             uint32_t q = wave_first[w].p;
             // insert (c, q) into the sorted top 4; whatever falls off goes to the threshold
@@ -439,15 +438,17 @@ __device__ __forceinline__ void publish_candidates(int64_t c1, uint32_t p1, int6
 template <typename T, int RULE, bool OPT, bool REG, bool LPI, bool CAND>
 __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const ResidentParams<T> p)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lm[kMailboxLines * 16];
+    // mailbox staging: line 0 + one chunk of patch lines.  128 KB when LDS is not needed for the potentials (10 235 entries per chunk)
+    constexpr int kLines = LPI ? kMailboxLines : 8 * kMailboxLines, kChunk = kLines - 1;
+    __shared__ __attribute__((aligned(16))) uint32_t lm[kLines * 16];
     __shared__ __attribute__((aligned(16))) T lpi[LPI ? kLdsPiMax : 2];      // LPI: the whole potential vector lives here
     __shared__ uint32_t s_timeout;
-    const int tid = threadIdx.x;
-    const int my_i0 = blockIdx.x * kResidentTile + tid * kArcsPerThread;
+    const int tid = threadIdx.x, nt = (int)blockDim.x;        // 64..1024 threads: the host sizes the grid so that every CU gets a workgroup
+    const int my_i0 = blockIdx.x * nt * kArcsPerThread + tid * kArcsPerThread;
     TileData<T> mine;
     if (REG) load_tile<T>(p.src, p.tgt, p.cost, p.state, my_i0, mine);
     if (LPI) {
-        for (int i = tid; i < p.max_pi; i += kResidentThreads) lpi[i] = p.pi[i];
+        for (int i = tid; i < p.max_pi; i += nt) lpi[i] = p.pi[i];
         __syncthreads();
     }
     const T *const pi_view = LPI ? lpi : p.pi;
@@ -490,23 +491,31 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
         // ---- patches: final values, applied by EVERY workgroup before it reads (same argument as scan_kernel).
         // The entries beyond the header come in chunks of 255 lines (1275 entries), each line verified by its tag before use.
         bool torn = false;
-        for (int first = 1; first < lines; first += kChunkLines) {
-            const int chunk = lines - first < kChunkLines ? lines - first : kChunkLines;
-            {
+        for (int first = 1; first < lines; first += kChunk) {
+            const int chunk = lines - first < kChunk ? lines - first : kChunk;
+            for (int base = 0; base < chunk * 4; base += nt * 4) {      // up to four 16-byte reads per thread in flight, one wait
                 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                static_assert(kMailboxLines * 4 / kResidentThreads == 1, "one 16-byte read per thread and chunk");
-                v4u x = v4u{0u, 0u, 0u, 0u};
-                if (tid < chunk * 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x) : "v"(p.mailbox + ((size_t)first * 16 + tid * 4)) : "memory");
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)::"memory");
-                if (tid < chunk * 4) *reinterpret_cast<v4u *>(lm + 16 + tid * 4) = x;
+                v4u x[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    x[q] = v4u{0u, 0u, 0u, 0u};
+                    const int c = base + q * nt + tid;
+                    if (c < chunk * 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x[q]) : "v"(p.mailbox + ((size_t)first * 16 + c * 4)) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])::"memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = base + q * nt + tid;
+                    if (c < chunk * 4) *reinterpret_cast<v4u *>(lm + 16 + c * 4) = x[q];
+                }
             }
             __syncthreads();
             int bad = 0;
-            for (int l = tid; l < chunk; l += kResidentThreads) bad |= (lm[(1 + l) * 16 + 15] != seq);
+            for (int l = tid; l < chunk; l += nt) bad |= (lm[(1 + l) * 16 + 15] != seq);
             if (__syncthreads_or(bad)) { torn = true; break; }
             const int i_lo = (first - 1) * kMailboxPatchesPerLine;                    // entry index of the chunk's first entry
             const int i_hi = entries < i_lo + chunk * kMailboxPatchesPerLine ? entries : i_lo + chunk * kMailboxPatchesPerLine;
-            for (int i = i_lo + tid; i < i_hi; i += kResidentThreads) {
+            for (int i = i_lo + tid; i < i_hi; i += nt) {
                 const int rel = i - i_lo;
                 const uint32_t *q = lm + (1 + rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
                 if (i < extra_pi) {
@@ -532,8 +541,8 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
         if (torn) continue;                                // a line was still in flight: poll again (re-applying final values is harmless)
         if (n_pi | n_st) {
             if (tid == 0 && n_pi > 0) { const T v0 = (T)(int64_t)(((uint64_t)p0_hi << 32) | p0_lo); p.pi[p0_node] = v0; if (LPI) lpi[p0_node] = v0; }
-            if (tid == 64 && n_st > 0) { const int a = st_arc0 - p.base; if ((unsigned)a < (unsigned)p.count_padded) p.state[a] = (int8_t)st_val0; }
-            if (tid == 65 && n_st > 1) { const int a = st_arc1 - p.base; if ((unsigned)a < (unsigned)p.count_padded) p.state[a] = (int8_t)st_val1; }
+            if (tid == 1 && n_st > 0) { const int a = st_arc0 - p.base; if ((unsigned)a < (unsigned)p.count_padded) p.state[a] = (int8_t)st_val0; }
+            if (tid == 2 && n_st > 1) { const int a = st_arc1 - p.base; if ((unsigned)a < (unsigned)p.count_padded) p.state[a] = (int8_t)st_val1; }
             if (REG) {
                 if (n_st > 0) { const int a = st_arc0 - p.base - my_i0; if ((unsigned)a < 4u) mine.st4 = (mine.st4 & ~(0xFFu << (8 * a))) | ((st_val0 & 0xFFu) << (8 * a)); }
                 if (n_st > 1) { const int a = st_arc1 - p.base - my_i0; if ((unsigned)a < 4u) mine.st4 = (mine.st4 & ~(0xFFu << (8 * a))) | ((st_val1 & 0xFFu) << (8 * a)); }
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
             if (REG) {
                 eval_tile<T, RULE, OPT>(mine, pi_view, p.base + my_i0, p.m_s, next_arc, p.block_size, rstar, best);
             } else {
-                for (int i0 = my_i0; i0 < p.count_padded; i0 += gridDim.x * kResidentTile) {
+                for (int i0 = my_i0; i0 < p.count_padded; i0 += gridDim.x * nt * kArcsPerThread) {
                     TileData<T> d;
                     load_tile<T>(p.src, p.tgt, p.cost, p.state, i0, d);
                     eval_tile<T, RULE, OPT>(d, pi_view, p.base + i0, p.m_s, next_arc, p.block_size, rstar, best);
@@ -706,7 +715,7 @@ struct mcf_engine {
     size_t cand_ptr = 0;
     CandKey cand_thr{0, 0xFFFFFFFFu};             // p == kNone: the list holds every eligible arc
     uint32_t *h_exit = nullptr, *d_exit = nullptr;
-    int res_grid = 0;
+    int res_grid = 0, res_threads = kResidentThreads;
     hipEvent_t res_start = nullptr, res_stop = nullptr;
     // flush buffer for cold micro-benchmarks
     void *d_flush = nullptr;
@@ -914,13 +923,13 @@ uint32_t *alloc_bar_vram(int hip_device, size_t bytes)
     return (uint32_t *)ptr;
 }
 
-constexpr int kResidentMaxGrid = 256;       // one 1024-thread workgroup per CU: always co-resident
+constexpr int kResidentMaxGrid = 256;       // one workgroup (64..1024 threads) per CU: always co-resident, every CU gathers
 constexpr uint32_t kResidentIdleTicks = 25000000u;   // 0.25 s of s_memrealtime
 
 template <typename T, int RULE, bool OPT>
 void launch_resident_r(mcf_engine *e, const ResidentParams<T> &p)
 {
-    const dim3 grid(e->res_grid), block(kResidentThreads);
+    const dim3 grid(e->res_grid), block(e->res_threads);
     const bool lpi = e->lds_pi;
     if (e->cand_on) {     // candidates: Best Eligible, register-resident tiles only
         if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, true, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
@@ -1417,7 +1426,22 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         return mcf::fail(MCF_ERR_INVALID, "bad shard [%d, %d)", desc->shard_begin, desc->shard_end);
     }
     const int count = e->end - e->begin;
+    // geometry of the resident grid: as many workgroups as CUs (<= 256), each just wide enough to hold its share of the arcs in
+    // registers (4 per thread); above 1M arcs the workgroups are 1024 wide and loop over memory instead
+    {
+        const int64_t groups4 = ((int64_t)count + kArcsPerThread - 1) / kArcsPerThread;            // threads needed
+        int g = (int)std::min<int64_t>(kResidentMaxGrid, std::max<int64_t>(1, (groups4 + 63) / 64));
+        int64_t t = ((groups4 + g - 1) / g + 63) / 64 * 64;
+        t = std::max<int64_t>(64, std::min<int64_t>(t, kResidentThreads));
+        e->res_grid = g;
+        e->res_threads = (int)t;
+        e->resident_reg = (int64_t)g * t * kArcsPerThread >= count;
+    }
     e->count_padded = std::max(kPad, (count + kPad - 1) / kPad * kPad);
+    if (e->resident_reg) {
+        const int64_t need = (int64_t)e->res_grid * e->res_threads * kArcsPerThread;
+        if (need > e->count_padded) e->count_padded = (int)((need + kPad - 1) / kPad * kPad);
+    }
     e->block_size = desc->block_size > 0 ? desc->block_size : mcf::default_block_size(desc->search_arc_num, desc->semantics);
     e->unroll = count > (1 << 20) ? 2 : 1;
     if (const char *u = getenv("MCF_HIP_UNROLL")) { const int v = atoi(u); if (v == 1 || v == 2 || v == 4) e->unroll = v; }
@@ -1486,9 +1510,6 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
                 alignas(16) uint32_t zero[16] = {0};
                 for (int l = 0; l < e->mailbox_lines; ++l) mailbox_write_line(e->mailbox + 16 * (size_t)l, zero);
                 _mm_sfence();
-                const int tiles = e->count_padded / kResidentTile;
-                e->resident_reg = tiles <= kResidentMaxGrid;
-                e->res_grid = e->resident_reg ? tiles : kResidentMaxGrid;
                 e->resident_ok = true;
                 e->cand_on = (desc->flags & MCF_ENGINE_CANDIDATES) && e->resident_reg && desc->rule == MCF_RULE_BEST_ELIGIBLE &&
                              2 * (int64_t)desc->search_arc_num <= (int64_t)kCandMaxAvgDegree * desc->node_count;
@@ -1496,7 +1517,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         }
     }
     e->st.scan_workgroups = e->resident_ok ? e->res_grid : e->grid;
-    e->st.scan_threads = (e->resident_ok || e->lds_pi) ? kResidentThreads : kThreads;
+    e->st.scan_threads = e->resident_ok ? e->res_threads : (e->lds_pi ? kResidentThreads : kThreads);
     e->st.resident = e->resident_ok ? 1 : 0;
     e->st.candidates = e->cand_on ? 1 : 0;
     e->st.bytes_per_scan = (int64_t)(desc->int_width == 64 ? 17 : 13) * count + (int64_t)w * desc->node_count;

@@ -392,3 +392,44 @@ def test_bench_scan_reports_sane_durations():
     assert 500 < mn <= avg < 5e6
     f, e, c = eng.find_entering()
     assert (f, e, c) == O.scan_best(m_s, a["state"], a["cost"], a["src"], a["tgt"], a["pi"])
+
+
+def _random_problem(rng, n, m, supply_kind):
+    src = rng.integers(0, n, m).astype(np.int32)
+    tgt = rng.integers(0, n, m).astype(np.int32)
+    lower = np.where(rng.random(m) < 0.15, rng.integers(0, 4, m), 0).astype(np.int64)
+    upper = (lower + rng.integers(0, 12, m)).astype(np.int64)
+    upper[rng.random(m) < 0.1] = O.INF_CAP
+    cost = rng.integers(-6 if supply_kind == "negative" else 0, 20, m).astype(np.int64)
+    supply = np.zeros(n, np.int64)
+    k = max(1, n // 4)
+    s = rng.integers(1, 9, k)
+    supply[rng.choice(n, k, replace=False)] += s
+    supply[rng.choice(n, k, replace=False)] -= rng.permutation(s)
+    if supply_kind == "excess":
+        supply[rng.integers(0, n)] += 3          # unbalanced: whatever the C# solver makes of it, both sides must agree
+    return O.Problem(n, m, src, tgt, lower, upper, cost, supply)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_small_networks_all_outcomes(seed):
+    """Small random instances with lower bounds, infinite capacities, negative costs, self loops, parallel arcs, LEQ and GEQ:
+    status (Optimal / Infeasible / Unbounded), pivot sequence, cost, flows and potentials equal the oracle's."""
+    rng = np.random.default_rng(1000 + seed)
+    seen = set()
+    for trial in range(10):
+        n = int(rng.integers(2, 40))
+        m = int(rng.integers(1, 160))
+        kind = ["balanced", "negative", "excess"][trial % 3]
+        p = _random_problem(rng, n, m, kind)
+        stype = O.LEQ if trial % 4 == 3 else O.GEQ
+        sem, rule = [(O.SEM_CSHARP_OPT, O.RULE_BLOCK), (O.SEM_CSHARP, O.RULE_BEST), (O.SEM_CSHARP_OPT, O.RULE_FIRST), (O.SEM_CSHARP, O.RULE_BLOCK)][trial % 4]
+        flags = [0, M.ENGINE_DISPATCH, M.ENGINE_CANDIDATES][trial % 3]
+        o, st_o, tr_o, ns, st = _solve_both(p, sem, rule, supply_type=stype, flags=flags)
+        assert st == st_o, (seed, trial, st, st_o)
+        assert np.array_equal(ns.trace(), tr_o[: len(ns.trace())])
+        seen.add(st)
+        if st == M.SolverStatus.Optimal:
+            assert len(ns.trace()) == len(tr_o) and ns.get_total_cost() == o.total_cost
+            assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
+    assert seen       # at least something ran
