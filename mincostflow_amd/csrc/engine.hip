@@ -135,6 +135,9 @@ struct mcf_engine {
     std::vector<int64_t> dirty_vals;              // current potential of dirty_nodes[i]
     std::vector<int32_t> node_slot;               // position of a marked node in dirty_nodes
     bool dirty_overflow = false;                  // too much is dirty for the host to answer: only collect patches until the device searches
+    int patch_capacity = 0;                       // potential patches one request / one staged update can carry (2 * node_count + 256)
+    size_t dirty_marked = 0;                      // entries of dirty_nodes that were added with marking (before the overflow)
+    int dirty_blind_appends = 0;                  // lists appended without marking since then
     int64_t dirty_degree = 0;
     struct CandKey { int64_t c; uint32_t p; };
     std::vector<CandKey> cand_list;               // sorted; complete below cand_thr
@@ -260,10 +263,12 @@ int launch_scan(mcf_engine *e, bool with_patches, bool timed)
 
 // ship the pending patches with update_kernel (lists too long for the kernel arguments, or explicit flush)
 void cand_reset_dirty(mcf_engine *e);
+void cand_finish_dirty_fwd(mcf_engine *e);
 int flush_pending(mcf_engine *e)
 {
     if (e->cand_on && (!e->dirty_nodes.empty() || !e->dirty_arcs.empty())) {
         // candidate mode keeps its pending patches as "dirty" sets: turn them into lists (current values from the mirrors)
+        cand_finish_dirty_fwd(e);
         e->pend_node.swap(e->dirty_nodes);
         e->pend_val.swap(e->dirty_vals);
         e->pend_arc.assign(e->dirty_arcs.begin(), e->dirty_arcs.end());
@@ -374,7 +379,7 @@ int launch_resident(mcf_engine *e, uint32_t start_seq)
     p.src = e->d_src; p.tgt = e->d_tgt; p.cost = (const T *)e->d_cost; p.state = e->d_state; p.pi = (T *)e->d_pi;
     p.slots = e->d_slots; p.mailbox = e->mailbox; p.exit_word = e->d_exit;
     p.base = e->begin; p.count_padded = e->count_padded; p.m_s = e->d.search_arc_num; p.block_size = e->block_size;
-    p.start_seq = start_seq; p.idle_ticks = kResidentIdleTicks; p.max_pi = e->d.node_count; p.max_st = e->mailbox_max_st; p.poll_replicas = e->poll_replicas; p.poll_sleep = e->poll_sleep;
+    p.start_seq = start_seq; p.idle_ticks = kResidentIdleTicks; p.n_nodes = e->d.node_count; p.max_pi = e->patch_capacity; p.max_st = e->mailbox_max_st; p.poll_replicas = e->poll_replicas; p.poll_sleep = e->poll_sleep;
     const bool opt = e->d.semantics == MCF_SEM_OPTIMIZED;
     switch (e->d.rule) {
     case MCF_RULE_BEST_ELIGIBLE: launch_resident_r<T, MCF_RULE_BEST_ELIGIBLE, false>(e, p); break;
@@ -565,7 +570,39 @@ inline void cand_touch_node(mcf_engine *e, int u, int64_t value)
 }
 // a list the host will not evaluate anyway: just remember the patches (a repeated node is harmless, the later entry carries the later value
 // and the kernel applies entries in list order within a thread -- but two threads may race, so repeated nodes are de-duplicated at post time)
-inline void cand_note_overflow(mcf_engine *e) { e->dirty_overflow = true; }
+// Long lists (or anything after one) are appended without touching the marks: the device will search next anyway.  Entries may then
+// repeat a node; cand_finish_dirty() makes all entries of a node carry the same (current) value before the list is posted.
+inline void cand_append_blind(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values)
+{
+    if (!e->dirty_overflow) { e->dirty_overflow = true; e->dirty_marked = e->dirty_nodes.size(); }
+    if (e->dirty_nodes.size() + (size_t)count > (size_t)e->patch_capacity) {
+        // repeated long lists without a search in between: squeeze the repeats out (one entry per node, current value)
+        if (++e->cand_epoch == 0) { std::fill(e->node_mark.begin(), e->node_mark.end(), 0u); std::fill(e->arc_mark.begin(), e->arc_mark.end(), 0u); e->cand_epoch = 1; for (int a : e->dirty_arcs) e->arc_mark[a] = 1; }
+        else for (int a : e->dirty_arcs) e->arc_mark[a] = e->cand_epoch;
+        size_t keep = 0;
+        for (size_t i = 0; i < e->dirty_nodes.size(); ++i) {
+            const int u = e->dirty_nodes[i];
+            if (e->node_mark[u] == e->cand_epoch) continue;
+            e->node_mark[u] = e->cand_epoch;
+            e->dirty_nodes[keep] = u;
+            e->dirty_vals[keep] = e->pi[u];
+            ++keep;
+        }
+        e->dirty_nodes.resize(keep);
+        e->dirty_vals.resize(keep);
+        e->dirty_marked = keep;
+        e->dirty_blind_appends = 0;
+    }
+    e->dirty_nodes.insert(e->dirty_nodes.end(), nodes, nodes + count);
+    e->dirty_vals.insert(e->dirty_vals.end(), values, values + count);
+    e->dirty_blind_appends += 1;
+}
+inline void cand_finish_dirty(mcf_engine *e)
+{
+    if (!e->dirty_overflow) return;
+    const size_t refresh = e->dirty_blind_appends > 1 ? e->dirty_nodes.size() : e->dirty_marked;
+    for (size_t i = 0; i < refresh; ++i) e->dirty_vals[i] = e->pi[e->dirty_nodes[i]];
+}
 void cand_touch_arc(mcf_engine *e, int a)
 {
     if (e->arc_mark[a] == e->cand_epoch) return;
@@ -586,6 +623,8 @@ inline void cand_eval(const mcf_engine *e, int a, mcf_engine::CandKey &best)
     const mcf_engine::CandKey k{rc, (uint32_t)a};
     if (best.p == kNone || cand_key_less(k, best)) best = k;
 }
+
+void cand_finish_dirty_fwd(mcf_engine *e) { cand_finish_dirty(e); }
 
 // true: *k holds the entering arc (or "none": the scan would find nothing either) without asking the device
 bool cand_try_host(mcf_engine *e, Key *k)
@@ -674,6 +713,8 @@ void cand_reset_dirty(mcf_engine *e)
     e->dirty_arcs.clear();
     e->dirty_degree = 0;
     e->dirty_overflow = false;
+    e->dirty_marked = 0;
+    e->dirty_blind_appends = 0;
     if (++e->cand_epoch == 0) {
         std::fill(e->node_mark.begin(), e->node_mark.end(), 0u);
         std::fill(e->arc_mark.begin(), e->arc_mark.end(), 0u);
@@ -690,6 +731,7 @@ int local_search(mcf_engine *e, Key *k)
         // ---- candidate cache: answer from the host when that is provably the scan's answer
         if (cand_try_host(e, k)) { e->st.searches += 1; e->st.host_decided += 1; return MCF_OK; }
         // the device searches: ship every node / arc touched since its last search, with their current values
+        cand_finish_dirty(e);
         e->pend_node.swap(e->dirty_nodes);
         e->pend_val.swap(e->dirty_vals);
         e->pend_arc.assign(e->dirty_arcs.begin(), e->dirty_arcs.end());
@@ -892,6 +934,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         const int tiles = e->count_padded / (e->unroll * kResidentTile);
         e->grid = std::max(1, std::min(tiles, desc->scan_workgroups > 0 ? desc->scan_workgroups : 256));
     }
+    e->patch_capacity = 2 * desc->node_count + 256;
     const size_t w = desc->int_width / 8;
     hipError_t err = hipSuccess;
     auto chk = [&](hipError_t x) { if (err == hipSuccess && x != hipSuccess) err = x; };
@@ -908,7 +951,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
     }
     for (int i = 0; i < 2 && err == hipSuccess; ++i) {
         mcf_engine::Staging &s = e->stage[i];
-        s.cap_nodes = desc->node_count;
+        s.cap_nodes = 2 * desc->node_count + 256;
         chk(hipHostMalloc((void **)&s.nodes, sizeof(int32_t) * s.cap_nodes, hipHostMallocMapped | hipHostMallocCoherent));
         chk(hipHostMalloc((void **)&s.values, sizeof(int64_t) * s.cap_nodes, hipHostMallocMapped | hipHostMallocCoherent));
         chk(hipHostMalloc((void **)&s.arcs, sizeof(int32_t) * 4096, hipHostMallocMapped | hipHostMallocCoherent));
@@ -936,7 +979,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         const bool whole = e->begin == 0 && e->end == desc->search_arc_num;
         if (want && whole && !(desc->flags & (MCF_ENGINE_TIME_EVERY_KERNEL | MCF_ENGINE_NO_INLINE_UPDATE))) {
             e->mailbox_max_st = 4096;
-            e->mailbox_lines = 2 + (desc->node_count + e->mailbox_max_st + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
+            e->mailbox_lines = 2 + (e->patch_capacity + e->mailbox_max_st + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
             if (const char *u = getenv("MCF_HIP_POLL_REPLICAS")) { const int v = atoi(u); if (v >= 1 && v <= kMaxReplicas) e->poll_replicas = v; }
             if (const char *u = getenv("MCF_HIP_POLL_SLEEP")) { const int v = atoi(u); if (v >= 0 && v <= 64) e->poll_sleep = v; }
             e->mailbox = alloc_bar_vram(desc->device, (size_t)kMailboxTail * 4 + (size_t)e->mailbox_lines * 64);
@@ -1095,8 +1138,15 @@ int mcf_engine_update_potential(mcf_engine *e, int32_t count, const int32_t *nod
             if ((unsigned)nodes[i] >= (unsigned)e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "node %d out of range", nodes[i]);
             if (e->d.int_width == 32 && !fits32(e->pi[nodes[i]] + sigma)) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d leaves int32; create the engine with int_width 64", nodes[i]);
         }
-        if (count > kCandMaxDirtyNodes) cand_note_overflow(e);
-        for (int i = 0; i < count; ++i) { const int64_t v = (e->pi[nodes[i]] += sigma); cand_touch_node(e, nodes[i], v); }
+        if (count > kCandMaxDirtyNodes || e->dirty_overflow) {
+            std::vector<int64_t> &tmp = e->pend_val;      // scratch: empty in candidate mode between searches
+            tmp.resize(count);
+            for (int i = 0; i < count; ++i) tmp[i] = (e->pi[nodes[i]] += sigma);
+            cand_append_blind(e, count, nodes, tmp.data());
+            tmp.clear();
+        } else {
+            for (int i = 0; i < count; ++i) { const int64_t v = (e->pi[nodes[i]] += sigma); cand_touch_node(e, nodes[i], v); }
+        }
         e->st.potential_nodes += count;
         return MCF_OK;
     }
@@ -1130,8 +1180,12 @@ int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes,
         if (narrow && !fits32(values[i])) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d leaves int32; create the engine with int_width 64", nodes[i]);
     }
     if (e->cand_on) {                 // the mirror stays authoritative in candidate mode
-        if (count > kCandMaxDirtyNodes) cand_note_overflow(e);
-        for (int i = 0; i < count; ++i) { e->pi[nodes[i]] = values[i]; cand_touch_node(e, nodes[i], values[i]); }
+        if (count > kCandMaxDirtyNodes || e->dirty_overflow) {
+            for (int i = 0; i < count; ++i) e->pi[nodes[i]] = values[i];
+            cand_append_blind(e, count, nodes, values);
+        } else {
+            for (int i = 0; i < count; ++i) { e->pi[nodes[i]] = values[i]; cand_touch_node(e, nodes[i], values[i]); }
+        }
         e->st.potential_nodes += count;
         return MCF_OK;
     }

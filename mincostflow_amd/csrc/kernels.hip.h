@@ -342,7 +342,8 @@ struct ResidentParams {
     uint32_t *exit_word;        // pinned host memory: [0] exit code, [1] requests served, [2..3] scan ticks of workgroup 0
     int32_t base, count_padded, m_s, block_size;
     uint32_t start_seq, idle_ticks;
-    int32_t max_pi;             // potential patches the mailbox can hold (= node_count)
+    int32_t n_nodes;            // length of pi
+    int32_t max_pi;             // potential patches the mailbox can hold
     int32_t max_st;             // state patches it can hold
     int32_t poll_replicas, poll_sleep;
 };
@@ -485,8 +486,9 @@ __device__ __forceinline__ void publish_candidates(int64_t c1, uint32_t p1, int6
 template <typename T, int RULE, bool OPT, bool REG, bool LPI, bool CAND>
 __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const ResidentParams<T> p)
 {
-    // mailbox staging: line 0 + one chunk of patch lines.  128 KB when LDS is not needed for the potentials (10 235 entries per chunk)
-    constexpr int kLines = LPI ? kMailboxLines : 8 * kMailboxLines, kChunk = kLines - 1;
+    // mailbox staging: line 0 + one chunk of patch lines: 16 KB next to LDS-resident potentials, else 32 KB (2555 entries per chunk);
+    // kept small so that several resident grids (independent solves) can share a CU
+    constexpr int kLines = LPI ? kMailboxLines : 2 * kMailboxLines, kChunk = kLines - 1;
     __shared__ __attribute__((aligned(16))) uint32_t lm[kLines * 16];
     __shared__ __attribute__((aligned(16))) T lpi[LPI ? kLdsPiMax : 2];      // LPI: the whole potential vector lives here
     __shared__ uint32_t s_timeout;
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
     TileData<T> mine;
     if (REG) load_tile<T>(p.src, p.tgt, p.cost, p.state, my_i0, mine);
     if (LPI) {
-        for (int i = tid; i < p.max_pi; i += nt) lpi[i] = p.pi[i];
+        for (int i = tid; i < p.n_nodes; i += nt) lpi[i] = p.pi[i];
         __syncthreads();
     }
     const T *const pi_view = LPI ? lpi : p.pi;

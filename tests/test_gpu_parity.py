@@ -359,6 +359,15 @@ def test_candidate_cache_answers_most_searches_and_changes_nothing():
             eng.update_potential(nodes, sigma)
         else:
             eng.set_potential(nodes, a["pi"][nodes])
+    # several long lists in a row without a search in between (repeats are squeezed out before the list can outgrow the mailbox)
+    for rep in range(7):
+        nodes = rng.choice(n, size=8000, replace=False).astype(np.int32)
+        a["pi"][nodes] += rep + 1
+        if rep % 2:
+            eng.update_potential(nodes, rep + 1)
+        else:
+            eng.set_potential(nodes, a["pi"][nodes])
+    assert eng.find_entering() == O.scan_best(m_s, a["state"], a["cost"], a["src"], a["tgt"], a["pi"])
     st2 = eng.stats()
     assert st2["host_decided"] > 50 and st2["resident_requests"] > 5, st2
     assert np.array_equal(eng.download_pi(), a["pi"]) and np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
