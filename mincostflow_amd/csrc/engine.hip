@@ -504,7 +504,9 @@ int collect(mcf_engine *e, int grid, Key *out)
     const int na = e->next_arc >= e->d.search_arc_num ? 0 : e->next_arc;
     for (int g = 0; g < grid; ++g) {
         uint64_t spins = 0;
-        while (slots[(size_t)g * stride].tag != seq) {
+        auto ready = [&](const volatile Slot &r) { const int64_t c = r.c; const uint32_t q = r.p; return r.tag == record_tag(seq, c, q); };
+        while (!(ready(slots[(size_t)g * stride]) && ready(slots[(size_t)g * stride + 1]) && slots[(size_t)g * stride].c == slots[(size_t)g * stride + 1].c &&
+                 slots[(size_t)g * stride].p == slots[(size_t)g * stride + 1].p)) {
             _mm_pause();
             if (e->resident_running && (spins & 0xFFF) == 0xFFF && ((const volatile uint32_t *)e->h_exit)[0] != 0) {
                 // the resident grid left on its idle timeout while this request was on its way: start it again, it will
@@ -666,7 +668,7 @@ int cand_collect(mcf_engine *e, Key *out)
         uint64_t spins = 0;
         for (;;) {
             bool all = true;
-            for (int r = 0; r <= kCandPerGroup; ++r) all = all && rec[r].tag == seq;
+            for (int r = 0; r < kCandRecords; ++r) { const int64_t c = rec[r].c; const uint32_t q = rec[r].p; all = all && rec[r].tag == record_tag(seq, c, q); }
             if (all) break;
             _mm_pause();
             if (e->resident_running && (spins & 0xFFF) == 0xFFF && ((const volatile uint32_t *)e->h_exit)[0] != 0) {

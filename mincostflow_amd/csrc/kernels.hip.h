@@ -37,6 +37,14 @@ struct alignas(16) Slot {
     uint32_t tag;
 };
 
+// tag of a record = request number mixed with the payload: a host that reads a record whose halves belong to different writes
+// (a torn 16-byte store) sees a tag that does not verify and keeps waiting
+__host__ __device__ inline uint32_t record_tag(uint32_t seq, int64_t c, uint32_t p)
+{
+    const uint64_t u = (uint64_t)c;
+    return seq ^ (uint32_t)u ^ (uint32_t)(u >> 32) ^ ((p << 13) | (p >> 19));
+}
+
 struct Key {
     int64_t c;
     uint32_t r;   // Block Search: rank of the block in scan order (doubled, +1 for the wrapped half in OPTIMIZED)
@@ -244,7 +252,7 @@ __device__ __forceinline__ void publish_best(Key best, Slot *slot, uint32_t tag,
         out.x = (uint32_t)(uint64_t)k.c;
         out.y = (uint32_t)((uint64_t)k.c >> 32);
         out.z = k.p;
-        out.w = tag;
+        out.w = record_tag(tag, k.c, k.p);
         // full_line: lanes 0..3 write the record four times = one whole 64-byte line (no partial-line write on the host side)
         const int lanes = full_line ? 4 : 1;
         if (tid < lanes) {
@@ -394,7 +402,7 @@ __device__ __forceinline__ void store_record_system(Slot *slot, int64_t c, uint3
     out.x = (uint32_t)(uint64_t)c;
     out.y = (uint32_t)((uint64_t)c >> 32);
     out.z = p;
-    out.w = tag;
+    out.w = record_tag(tag, c, p);
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(slot), "v"(out) : "memory");
 }
 
