@@ -121,6 +121,28 @@ def microbench():
     return out
 
 
+def pin_near_gpu(dev):
+    """Best effort: run this rank's host thread on the cores of the GPU's NUMA node (the pivot loop is a host <-> device latency chain)."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return node
+    except Exception:
+        pass
+    return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -144,6 +166,7 @@ def main():
         else:
             dist.init_process_group("gloo")
     local_rank = dev
+    numa = pin_near_gpu(dev)
 
     g, rule, width, desc = workload(args.workload, SEED + rank)
 
@@ -271,7 +294,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": desc, "instance": f"netgen_like(seed={SEED}+rank)" if args.workload != "config4" else "assignment(seed 42)",
                    "pivot_rule": {0: "FirstEligible", 1: "BestEligible", 2: "BlockSearch"}[rule], "semantics": "EnableOptimizedPivot(true)",
-                   "search_arcs": mets[0]["search_arc_num"], "parallelism": "1 solve per GPU" if args.gpus > 1 else "1 GPU"},
+                   "search_arcs": mets[0]["search_arc_num"], "parallelism": "1 solve per GPU" if args.gpus > 1 else "1 GPU", "host_thread_numa_node": numa},
         "solve_ms": sum(m["loop_us"] for m in mets) / len(mets) / 1e3,
         "solve_ms_incl_setup_and_upload": sum(m["total_solve_us"] for m in mets) / len(mets) / 1e3,
         "pivots_per_solve": pivots / len(mets),
