@@ -46,8 +46,9 @@ struct mcf_ns {
     int n_state = 0;
     int32_t st_arc[2] = {0, 0};
     int8_t st_val[2] = {0, 0};
-    std::vector<int32_t> moved;
+    std::vector<int32_t> moved;       // capacity n+1, the first moved_n entries are valid
     std::vector<int64_t> moved_val;   // their new potentials
+    int moved_n = 0;
     int64_t sigma = 0;
     // engine + sharding
     mcf_engine *engine = nullptr;
@@ -267,14 +268,52 @@ void rehang_subtree(mcf_ns *s)
 
 // ---- NS.cs:1185-1209: host copy of pi is kept current (sigma needs pi[v_in], pi[u_in]); the node list is what
 // mcf_engine_update_potential ships to the device.
+// The subtree of u_in is the thread segment u_in .. LastSucc[u_in], SuccNum[u_in] nodes long; NS.cs:1196-1208 walks it front to back,
+// one dependent load per node, which is what a big subtree costs.  Here the same set of nodes is visited along several independent
+// chains at once: every segment is walked from both ends (Thread forwards, RevThread backwards), and a long segment is split at its
+// front cursor a into the subtree of a (a .. LastSucc[a], SuccNum[a] nodes) and the rest, which costs two loads.  The order of the
+// resulting list is irrelevant to the engine (final values), and pi[] ends up exactly as in the reference.
 void shift_potentials(mcf_ns *s)
 {
     s->sigma = s->pi[s->v_in] - s->pi[s->u_in] - s->par_dir[s->u_in] * s->cost[s->in_arc];
-    const int stop = s->nxt[s->fin[s->u_in]];
-    for (int u = s->u_in; u != stop; u = s->nxt[u]) {
-        const int64_t v = (s->pi[u] += s->sigma);
-        s->moved.push_back(u);
-        s->moved_val.push_back(v);
+    const int64_t sigma = s->sigma;
+    const int count = s->sub[s->u_in];
+    s->moved_n = count;
+    int32_t *const nodes = s->moved.data();
+    int64_t *const vals = s->moved_val.data();
+    int64_t *const pi = s->pi.data();
+    const int32_t *const nxt = s->nxt.data(), *const prv = s->prv.data(), *const sub = s->sub.data(), *const fin = s->fin.data();
+    struct Seg { int a, b, lo, hi; };          // cursors and the output range [lo, hi] they fill towards each other
+    constexpr int kSegs = 4, kSplitMin = 256;
+    Seg seg[kSegs];
+    int n_seg = 1;
+    seg[0] = Seg{s->u_in, fin[s->u_in], 0, count - 1};
+    while (n_seg > 0) {
+        if (n_seg < kSegs) {                   // split the longest segment when its front cursor roots a middle-sized subtree
+            int big = 0;
+            for (int i = 1; i < n_seg; ++i) if (seg[i].hi - seg[i].lo > seg[big].hi - seg[big].lo) big = i;
+            const int left = seg[big].hi - seg[big].lo + 1;
+            if (left >= kSplitMin) {
+                const int a = seg[big].a, k = sub[a];
+                if (4 * k >= left && 4 * k <= 3 * left) {
+                    const int last = fin[a];
+                    seg[n_seg++] = Seg{nxt[last], seg[big].b, seg[big].lo + k, seg[big].hi};
+                    seg[big].b = last;
+                    seg[big].hi = seg[big].lo + k - 1;
+                }
+            }
+        }
+        for (int i = 0; i < n_seg; ++i) {
+            Seg &g = seg[i];
+            if (g.lo < g.hi) {
+                const int a = g.a, b = g.b;
+                nodes[g.lo] = a; vals[g.lo] = (pi[a] += sigma); g.a = nxt[a]; ++g.lo;
+                nodes[g.hi] = b; vals[g.hi] = (pi[b] += sigma); g.b = prv[b]; --g.hi;
+            } else {
+                if (g.lo == g.hi) { const int a = g.a; nodes[g.lo] = a; vals[g.lo] = (pi[a] += sigma); }
+                seg[i] = seg[--n_seg];         // done: the last segment takes its slot (and its turn comes in the next round)
+            }
+        }
     }
 }
 
@@ -282,8 +321,7 @@ void shift_potentials(mcf_ns *s)
 bool pivot(mcf_ns *s, int arc, double *t_tree, double *t_pot)
 {
     s->in_arc = arc;
-    s->moved.clear();
-    s->moved_val.clear();
+    s->moved_n = 0;
     s->sigma = 0;
     find_join(s);
     const bool change = find_leaving(s);
@@ -363,7 +401,7 @@ int mcf_ns_create(mcf_ns **out, int32_t node_count, int32_t arc_count, const int
     s->orig_lower.assign(arc_count, 0);
     s->state.assign(A, 0);
     s->supply.assign(N, 0); s->pi.assign(N, 0);
-    s->par.assign(N, -1); s->par_arc.assign(N, -1); s->nxt.assign(N, 0); s->prv.assign(N, 0);
+    s->par.assign(N, -1); s->par_arc.assign(N, -1); s->nxt.assign(N, 0); s->prv.assign(N, 0); s->moved.assign(N, 0); s->moved_val.assign(N, 0);
     s->sub.assign(N, 0); s->fin.assign(N, 0); s->par_dir.assign(N, 0); s->scratch.assign(N + 1, 0);
     *out = s;
     return MCF_OK;
@@ -499,7 +537,7 @@ int mcf_ns_last_pivot(mcf_ns *s, int32_t *n_state, int32_t arcs[2], int8_t state
     if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
     if (n_state) *n_state = s->n_state;
     for (int i = 0; i < s->n_state; ++i) { if (arcs) arcs[i] = s->st_arc[i]; if (states) states[i] = s->st_val[i]; }
-    if (n_nodes) *n_nodes = (int32_t)s->moved.size();
+    if (n_nodes) *n_nodes = (int32_t)s->moved_n;
     if (nodes) *nodes = s->moved.data();
     if (sigma) *sigma = s->sigma;
     return MCF_OK;
@@ -577,10 +615,10 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         if (pivot(s, arc, &t_tree, &t_pot)) { s->status = MCF_UNBOUNDED; break; }
         const double t1 = mcf::now_ns();
         rc = mcf_engine_patch_state(s->engine, s->n_state, s->st_arc, s->st_val);
-        if (!rc && !s->moved.empty()) rc = mcf_engine_set_potential(s->engine, (int32_t)s->moved.size(), s->moved.data(), s->moved_val.data());
+        if (!rc && s->moved_n) rc = mcf_engine_set_potential(s->engine, (int32_t)s->moved_n, s->moved.data(), s->moved_val.data());
         t_pot += mcf::now_ns() - t1;
         if (rc) return rc;
-        s->metrics.potential_nodes += (int64_t)s->moved.size();
+        s->metrics.potential_nodes += (int64_t)s->moved_n;
     }
     mcf_engine_park(s->engine);      // a resident scan grid must not outlive Solve()
     s->trace_len = std::min(it, s->trace_cap);
