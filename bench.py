@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--workload", default="config3", choices=["config2", "config3", "config4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
+    ap.add_argument("--no-validator", action="store_true", help="skip the SolutionValidator measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline sample")
     ap.add_argument("--sharded-pivots", type=int, default=0, help="N>1: also time this many pivots of config 5 sharded over RCCL")
     ap.add_argument("--dispatch", action="store_true", help="one scan dispatch per search instead of the resident grid")
@@ -118,6 +119,43 @@ def microbench():
     ms = it["search_arc_num"]
     run("NETGEN-like 1M nodes / 8M arcs start basis (config 5 arrays)", g5.node_count + 1, ms, it["source"][:ms], it["target"][:ms],
         it["cost"][:ms], it["state"][:ms], it["pi"], "generator order: grouped by tail, random heads")
+    return out
+
+
+def validator_bench(M, g, ns, local_rank, with_cpu):
+    """SolutionValidator on the solved instance and on config 5's shape: inputs resident, HIP events around the run."""
+    import numpy as np
+    out = []
+
+    def one(label, n, m, src, tgt, lower, upper, cost, supply, flow, pi, reported, cpu):
+        v = M.SolutionValidator(n, m, local_rank).upload_network(src, tgt, lower, upper, cost, supply).upload_solution(flow, pi)
+        runs = [v.run(M.SupplyType.Geq, reported) for _ in range(12)][2:]
+        us = sum(r["kernel_us"] for r in runs) / len(runs)
+        r = runs[-1]
+        entry = {"case": label, "arcs": m, "nodes": n, "valid": r["valid"], "objective": r["objective"], "dual_cost": r["dual_cost"],
+                 "kernels": "memset + validate_arcs + validate_nodes + validate_fold", "avg_us": us, "min_us": min(x["kernel_us"] for x in runs),
+                 "algorithmic_bytes": r["algorithmic_bytes"], "achieved_GBps": r["algorithmic_bytes"] / us / 1e3,
+                 "frac_of_hbm_peak": r["algorithmic_bytes"] / us / 1e3 / HBM_PEAK_GBS}
+        if cpu:
+            from oracle import validator as V
+            t0 = time.perf_counter()
+            ref = V.validate(n, src, tgt, lower, upper, cost, supply, V.GEQ, flow, pi, reported)
+            entry["cpu_restatement_ms"] = (time.perf_counter() - t0) * 1e3
+            entry["cpu_kind"] = "port (numpy, 1 thread)"
+            entry["matches_cpu"] = all(ref[k] == r[k] for k in ("valid", "objective", "dual_cost", "errors", "first"))
+        out.append(entry)
+        del v
+
+    one("config-3 optimum (the timed solve's flows and potentials)", g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply,
+        ns.flows(), ns.potentials(), ns.get_total_cost(), with_cpu)
+    rng = np.random.default_rng(8)
+    n, m = 1_000_000, 8_000_000
+    src = rng.integers(0, n, m, dtype=np.int32); tgt = rng.integers(0, n, m, dtype=np.int32)
+    upper = rng.integers(1, 1000, m).astype(np.int64); cost = rng.integers(1, 10001, m).astype(np.int64)
+    flow = np.where(rng.random(m) < 0.12, rng.integers(0, 1000, m), 0).astype(np.int64)          # ~n arcs carry flow, like a basis
+    pi = -rng.integers(0, 10 ** 7, n).astype(np.int64)
+    supply = np.zeros(n, np.int64); np.add.at(supply, src, flow); np.subtract.at(supply, tgt, flow)
+    one("config-5 shape, random solution-like vectors", n, m, src, tgt, np.zeros(m, np.int64), upper, cost, supply, flow, pi, 0, with_cpu)
     return out
 
 
@@ -344,6 +382,8 @@ def main():
             line["cpu_baseline_block_search"] = blk       # the reference's default rule, for the cross-rule comparison
     if not args.no_microbench and args.gpus == 1:
         line["scan_microbench"] = microbench()
+    if not args.no_validator and args.gpus == 1:
+        line["solution_validator"] = validator_bench(M, g, solvers[0], local_rank, not args.no_cpu_baseline)
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

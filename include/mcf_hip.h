@@ -20,6 +20,9 @@
  *      argument meaning mirror the reference class.  There is NO CPU entering-arc search in this
  *      library: mcf_ns_solve() fails with MCF_ERR_NO_DEVICE when no HIP device is usable.
  *
+ *  (3) mcf_validator_* / mcf_ns_validate -- the reference's SolutionValidator (Validation/SolutionValidator.cs)
+ *      as two device reductions; like the search it has no CPU path in this library.
+ *
  * Conventions: every function returns 0 (MCF_OK) or a negative mcf_status; the message is available
  * from mcf_last_error() (thread-local).  Nothing throws across the ABI.  Host arrays are borrowed
  * for the duration of the call only.  One engine / one solver = one host thread at a time (the
@@ -267,7 +270,54 @@ MCF_API int mcf_ns_last_pivot(mcf_ns *s, int32_t *n_state, int32_t arcs[2], int8
                               const int32_t **nodes, int64_t *sigma);
 
 /* ------------------------------------------------------------------------------------------------
- * Problem sources (build-owned; the reference ships NETGEN outputs but no generator: SURVEY.md F6, 8d)
+ * (3) Solution validator on the device: the checks of
+ *     src/MinCostFlow.Core/Lemon/Validation/SolutionValidator.cs as reductions over the arcs and the nodes.
+ *     Same arithmetic as the reference (C# long, unchecked: it wraps).  Instead of message strings the result
+ *     carries, per check, the number of messages the reference would add and the lowest arc / node id among them.
+ * ---------------------------------------------------------------------------------------------- */
+typedef enum mcf_validation_kind {
+    MCF_VAL_CONSERVATION = 0,   /* node: net flow vs supply under the supply type        SolutionValidator.cs:75-99   */
+    MCF_VAL_LOWER = 1,          /* arc : flow < lower                                    :111-115 */
+    MCF_VAL_UPPER = 2,          /* arc : flow > upper                                    :117-121 */
+    MCF_VAL_SLACK_POS = 3,      /* arc : reduced cost > 0 but flow != lower              :164-168 */
+    MCF_VAL_SLACK_NEG = 4,      /* arc : reduced cost < 0 but flow != upper              :170-174 */
+    MCF_VAL_NODE_DUAL = 5,      /* node: sign of pi against the supply type              :203-207, :218-222 */
+    MCF_VAL_NODE_SLACK = 6,     /* node: pi != 0 but net flow != supply                  :208-213, :223-228 */
+    MCF_VAL_OBJECTIVE = 7,      /* sum flow*cost != reported cost                        :257-262 */
+    MCF_VAL_DUAL_COST = 8,      /* dual cost != reported cost                            :333-339 */
+    MCF_VAL_STATUS = 9,         /* solver status is not Optimal (nothing else is checked) :28-33 */
+    MCF_VAL_KINDS = 10
+} mcf_validation_kind;
+/* a third supply type for the validator only: the reference's `_ =>` equality branch (SolutionValidator.cs:83) */
+#define MCF_SUPPLY_EQ 2
+
+typedef struct mcf_validation {
+    int32_t valid;                      /* ValidationResult.IsValid: no message at all */
+    int32_t supply_type;
+    int64_t objective;                  /* calculatedCost (:232-255) */
+    int64_t dual_cost;                  /* ValidationResult.DualCost (:270-331) */
+    int64_t errors[MCF_VAL_KINDS];
+    int64_t first[MCF_VAL_KINDS];       /* lowest failing arc / node id, -1 when the check passes */
+    double kernel_us;                   /* HIP events around one run: memset + validate_arcs + validate_nodes + validate_fold */
+    int64_t algorithmic_bytes;          /* 40 B per arc + 40 B per node, see DESIGN.md */
+} mcf_validation;
+
+typedef struct mcf_validator mcf_validator;
+MCF_API int mcf_validator_create(mcf_validator **out, int32_t device, int32_t node_count, int32_t arc_count);
+MCF_API void mcf_validator_destroy(mcf_validator *v);
+/* Host arrays, copied.  The network (first six arrays) and the solution (flow, pi) may be uploaded separately:
+ * pass NULL for everything that stays as it is on the device. */
+MCF_API int mcf_validator_upload(mcf_validator *v, const int32_t *source, const int32_t *target, const int64_t *lower,
+                                 const int64_t *upper, const int64_t *cost, const int64_t *supply, const int64_t *flow,
+                                 const int64_t *pi);
+MCF_API int mcf_validator_run(mcf_validator *v, int32_t supply_type, int64_t reported_cost, mcf_validation *out);
+/* SolutionValidator(graph, solver).Validate() for a solver of this library: reads what the reference's validator
+ * reads through the solver's getters (GetFlow, GetPotential, GetArcLowerBound = the original lower bound,
+ * GetArcUpperBound = the bound as mutated by Solve(), NS.cs:519-527, difference D11) */
+MCF_API int mcf_ns_validate(mcf_ns *s, mcf_validation *out);
+
+/* ------------------------------------------------------------------------------------------------
+ * (4) Problem sources (build-owned; the reference ships NETGEN outputs but no generator: SURVEY.md F6, 8d)
  * ---------------------------------------------------------------------------------------------- */
 
 typedef struct mcf_problem {

@@ -65,6 +65,20 @@ class NsMetrics(C.Structure):
         return d
 
 
+VALIDATION_KINDS = ("conservation", "lower", "upper", "slack_pos", "slack_neg", "node_dual", "node_slack", "objective", "dual_cost", "status")
+
+
+class Validation(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("supply_type", C.c_int32), ("objective", C.c_int64), ("dual_cost", C.c_int64),
+                ("errors", C.c_int64 * len(VALIDATION_KINDS)), ("first", C.c_int64 * len(VALIDATION_KINDS)),
+                ("kernel_us", C.c_double), ("algorithmic_bytes", C.c_int64)]
+
+    def as_dict(self):
+        return {"valid": int(self.valid), "supply_type": int(self.supply_type), "objective": int(self.objective), "dual_cost": int(self.dual_cost),
+                "errors": dict(zip(VALIDATION_KINDS, map(int, self.errors))), "first": dict(zip(VALIDATION_KINDS, map(int, self.first))),
+                "kernel_us": float(self.kernel_us), "algorithmic_bytes": int(self.algorithmic_bytes)}
+
+
 class ProblemStruct(C.Structure):
     _fields_ = [("node_count", C.c_int32), ("arc_count", C.c_int32), ("source", C.POINTER(C.c_int32)),
                 ("target", C.POINTER(C.c_int32)), ("lower", C.POINTER(C.c_int64)), ("upper", C.POINTER(C.c_int64)),
@@ -138,6 +152,11 @@ SIGNATURES = {
                                   _P(_P(C.c_int64)), _P(_P(C.c_int8)), _P(_P(C.c_int64))]),
     "mcf_ns_last_pivot": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int8), _P(C.c_int32),
                                     _P(_P(C.c_int32)), _P(C.c_int64)]),
+    "mcf_validator_create": (C.c_int, [_P(C.c_void_p), C.c_int32, C.c_int32, C.c_int32]),
+    "mcf_validator_destroy": (None, [C.c_void_p]),
+    "mcf_validator_upload": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8),
+    "mcf_validator_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, _P(Validation)]),
+    "mcf_ns_validate": (C.c_int, [C.c_void_p, _P(Validation)]),
     "mcf_problem_free": (None, [_P(ProblemStruct)]),
     "mcf_gen_netgen_like": (C.c_int, [_P(ProblemStruct), C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int64, C.c_int64, C.c_int64, C.c_int64]),

@@ -687,6 +687,29 @@ int mcf_ns_get_arc_upper_bound(mcf_ns *s, int32_t arc, int64_t *upper)
     *upper = s->upper[arc];
     return MCF_OK;
 }
+// SolutionValidator(graph, solver).Validate() (SolutionValidator.cs:20-52) with the checks run on the device
+int mcf_ns_validate(mcf_ns *s, mcf_validation *out)
+{
+    if (!s || !out) return mcf::fail(MCF_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof(*out));
+    for (int k = 0; k < MCF_VAL_KINDS; ++k) out->first[k] = -1;
+    out->supply_type = s->supply_type;
+    if (s->status != MCF_OPTIMAL) {                      // :28-33: nothing else is looked at
+        out->errors[MCF_VAL_STATUS] = 1;
+        out->first[MCF_VAL_STATUS] = 0;
+        return MCF_OK;
+    }
+    mcf_validator *v = nullptr;
+    int rc = mcf_validator_create(&v, s->device, s->n, s->m);
+    if (rc) return rc;
+    int64_t total = 0;                                   // GetTotalCost(), NS.cs:452-465
+    for (int e = 0; e < s->m; ++e) total = (int64_t)((uint64_t)total + (uint64_t)s->flow[e] * (uint64_t)s->cost[e]);
+    rc = mcf_validator_upload(v, s->tail.data(), s->head.data(), s->orig_lower.data(), s->upper.data(), s->cost.data(), s->supply.data(),
+                              s->flow.data(), s->pi.data());
+    if (!rc) rc = mcf_validator_run(v, s->supply_type, total, out);
+    mcf_validator_destroy(v);
+    return rc;
+}
 int mcf_ns_get_metrics(mcf_ns *s, mcf_ns_metrics *out)
 {
     if (!s || !out) return mcf::fail(MCF_ERR_INVALID, "null argument");

@@ -191,6 +191,9 @@ class NetworkSimplex:
     def get_metrics(self) -> dict:
         m = L.NsMetrics(); L.check(L.lib().mcf_ns_get_metrics(self._h, C.byref(m))); return m.as_dict()
 
+    def validate(self) -> dict:                                  # SolutionValidator(graph, solver).Validate()
+        v = L.Validation(); L.check(L.lib().mcf_ns_validate(self._h, C.byref(v))); return v.as_dict()
+
     # --- the sequential half on its own (what a C# host keeps); never searches for an entering arc
     def begin(self) -> int:
         st = C.c_int32(); L.check(L.lib().mcf_ns_begin(self._h, C.byref(st))); return st.value
@@ -219,6 +222,48 @@ class NetworkSimplex:
         nd = np.ctypeslib.as_array(nodes, shape=(nn.value,)).copy() if nn.value else np.zeros(0, np.int32)
         return dict(state_arcs=np.array(arcs[: ns.value], np.int32), state_values=np.array(states[: ns.value], np.int8),
                     nodes=nd, sigma=sigma.value)
+
+
+class SolutionValidator:
+    """The reference's SolutionValidator checks as device reductions (mcf_validator_* of include/mcf_hip.h)."""
+
+    def __init__(self, node_count: int, arc_count: int, device: int = 0):
+        self.node_count, self.arc_count = int(node_count), int(arc_count)
+        self._h = C.c_void_p()
+        L.check(L.lib().mcf_validator_create(C.byref(self._h), device, self.node_count, self.arc_count))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            L.lib().mcf_validator_destroy(h)
+            self._h = None
+
+    def _ptrs(self, arrays, kinds, lengths):
+        keep, out = [], []
+        for a, dt, k in zip(arrays, kinds, lengths):
+            if a is None:
+                out.append(None)
+                continue
+            a = np.ascontiguousarray(a, dt)
+            if a.shape != (k,):
+                raise ValueError(f"expected an array of {k} entries, got {a.shape}")
+            keep.append(a)
+            out.append(a.ctypes.data_as(C.c_void_p))
+        return keep, out
+
+    def upload_network(self, source, target, lower, upper, cost, supply):
+        m, n = self.arc_count, self.node_count
+        keep, p = self._ptrs((source, target, lower, upper, cost, supply), (np.int32, np.int32, np.int64, np.int64, np.int64, np.int64), (m, m, m, m, m, n))
+        L.check(L.lib().mcf_validator_upload(self._h, *p, None, None))
+        return self
+
+    def upload_solution(self, flow, pi):
+        keep, p = self._ptrs((flow, pi), (np.int64, np.int64), (self.arc_count, self.node_count))
+        L.check(L.lib().mcf_validator_upload(self._h, None, None, None, None, None, None, *p))
+        return self
+
+    def run(self, supply_type: int, reported_cost: int) -> dict:
+        v = L.Validation(); L.check(L.lib().mcf_validator_run(self._h, int(supply_type), int(reported_cost), C.byref(v))); return v.as_dict()
 
 
 class PivotEngine:
