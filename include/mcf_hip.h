@@ -338,6 +338,12 @@ MCF_API int mcf_gen_assignment(mcf_problem *out, uint64_t seed, int32_t n, int64
 /* DIMACS min-cost-flow reader / writer (Loaders/DimacsReader.cs:36-147; lemon/dimacs.h:129-186) */
 MCF_API int mcf_dimacs_read(mcf_problem *out, const char *path);
 MCF_API int mcf_dimacs_write(const mcf_problem *p, const char *path);
+/* .sol files (Loaders/SolutionLoader.cs:59-176 reader, :186-210 writer): "s COST", "f ARC FLOW" (0-based arc id, what the
+ * reference writes) or "f SRC DST FLOW" (1-based end points, what its bundled Gurobi solutions hold), "p NODE POTENTIAL".
+ * The reader fills flow[arc_count] (and pi[node_count] when given); end-point flows are split over parallel arcs by
+ * increasing cost.  pi may be NULL in both. */
+MCF_API int mcf_solution_write(const char *path, int64_t cost, int32_t arc_count, const int64_t *flow, int32_t node_count, const int64_t *pi);
+MCF_API int mcf_solution_read(const char *path, const mcf_problem *p, int64_t *cost, int32_t *has_cost, int64_t *flow, int64_t *pi, int32_t *has_pi);
 
 #ifdef __cplusplus
 }

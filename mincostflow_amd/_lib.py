@@ -163,6 +163,8 @@ SIGNATURES = {
     "mcf_gen_assignment": (C.c_int, [_P(ProblemStruct), C.c_uint64, C.c_int32, C.c_int64, C.c_int64]),
     "mcf_dimacs_read": (C.c_int, [_P(ProblemStruct), C.c_char_p]),
     "mcf_dimacs_write": (C.c_int, [_P(ProblemStruct), C.c_char_p]),
+    "mcf_solution_write": (C.c_int, [C.c_char_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mcf_solution_read": (C.c_int, [C.c_char_p, _P(ProblemStruct), _P(C.c_int64), _P(C.c_int32), C.c_void_p, C.c_void_p, _P(C.c_int32)]),
 }
 
 _lib = None

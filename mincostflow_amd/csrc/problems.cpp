@@ -228,4 +228,90 @@ int mcf_dimacs_write(const mcf_problem *p, const char *path)
     return MCF_OK;
 }
 
+// .sol files (Loaders/SolutionLoader.cs): "s COST", "f ARC FLOW" (0-based arc id, what SaveToFile writes, :186-210) or
+// "f SRC DST FLOW" (1-based end points, what the bundled Gurobi solutions hold, :115-139), "p NODE POTENTIAL" (:141-153).
+// The reference keeps end-point flows in a dictionary; here they are mapped onto arcs: the flow of a pair of end points goes to
+// its parallel arcs in order of increasing cost (then arc id), lower bounds first, each up to its capacity -- for an optimal
+// solution that is the only cost-minimal split up to ties.
+int mcf_solution_write(const char *path, int64_t cost, int32_t arc_count, const int64_t *flow, int32_t node_count, const int64_t *pi)
+{
+    if (!path || arc_count < 0 || node_count < 0 || (arc_count && !flow)) return mcf::fail(MCF_ERR_INVALID, "mcf_solution_write: bad arguments");
+    FILE *f = fopen(path, "w");
+    if (!f) return mcf::fail(MCF_ERR_IO, "%s: %s", path, strerror(errno));
+    fprintf(f, "s %lld\n", (long long)cost);
+    for (int e = 0; e < arc_count; ++e)
+        if (flow[e] != 0) fprintf(f, "f %d %lld\n", e, (long long)flow[e]);
+    if (pi)
+        for (int v = 0; v < node_count; ++v) fprintf(f, "p %d %lld\n", v, (long long)pi[v]);
+    if (fclose(f) != 0) return mcf::fail(MCF_ERR_IO, "%s: write failed", path);
+    return MCF_OK;
+}
+
+int mcf_solution_read(const char *path, const mcf_problem *p, int64_t *cost, int32_t *has_cost, int64_t *flow, int64_t *pi, int32_t *has_pi)
+{
+    if (!path || !p || !flow) return mcf::fail(MCF_ERR_INVALID, "mcf_solution_read: null argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return mcf::fail(MCF_ERR_IO, "%s: %s", path, strerror(errno));
+    const int n = p->node_count, m = p->arc_count;
+    std::fill(flow, flow + m, (int64_t)0);
+    if (pi) std::fill(pi, pi + n, (int64_t)0);
+    if (has_cost) *has_cost = 0;
+    if (has_pi) *has_pi = 0;
+    struct Pair { int32_t u, v; int64_t flow; };
+    std::vector<Pair> pairs;
+    char line[512];
+    int line_no = 0;
+    while (fgets(line, sizeof(line), f)) {
+        ++line_no;
+        char tag = 0;
+        long long v[3] = {0, 0, 0};
+        const int got = sscanf(line, " %c %lld %lld %lld", &tag, &v[0], &v[1], &v[2]);
+        if (got < 1 || tag == 'c') continue;
+        if (tag == 's' && got >= 2) {
+            if (cost) *cost = v[0];
+            if (has_cost) *has_cost = 1;
+        } else if (tag == 'f' && got == 3) {
+            if (v[0] < 0 || v[0] >= m) { fclose(f); return mcf::fail(MCF_ERR_IO, "%s:%d: arc id out of range", path, line_no); }
+            flow[v[0]] = v[1];
+        } else if (tag == 'f' && got == 4) {
+            if (v[0] < 1 || v[0] > n || v[1] < 1 || v[1] > n) { fclose(f); return mcf::fail(MCF_ERR_IO, "%s:%d: node id out of range", path, line_no); }
+            pairs.push_back(Pair{(int32_t)(v[0] - 1), (int32_t)(v[1] - 1), v[2]});
+        } else if (tag == 'p' && got >= 3) {
+            if (v[0] < 0 || v[0] >= n) { fclose(f); return mcf::fail(MCF_ERR_IO, "%s:%d: node id out of range", path, line_no); }
+            if (pi) pi[v[0]] = v[1];
+            if (has_pi) *has_pi = 1;
+        }
+    }
+    fclose(f);
+    if (pairs.empty()) return MCF_OK;
+    // arcs ordered by (source, target, cost, id); every pair of end points finds its run by binary search
+    std::vector<int32_t> order((size_t)m);
+    for (int e = 0; e < m; ++e) order[e] = e;
+    auto key_less = [&](int32_t a, int32_t b) {
+        if (p->source[a] != p->source[b]) return p->source[a] < p->source[b];
+        if (p->target[a] != p->target[b]) return p->target[a] < p->target[b];
+        if (p->cost[a] != p->cost[b]) return p->cost[a] < p->cost[b];
+        return a < b;
+    };
+    std::sort(order.begin(), order.end(), key_less);
+    for (const Pair &q : pairs) {
+        auto lo = std::partition_point(order.begin(), order.end(), [&](int32_t e) {
+            return p->source[e] < q.u || (p->source[e] == q.u && p->target[e] < q.v);
+        });
+        auto hi = lo;
+        while (hi != order.end() && p->source[*hi] == q.u && p->target[*hi] == q.v) ++hi;
+        if (lo == hi) return mcf::fail(MCF_ERR_IO, "%s: flow on %d -> %d, which is not an arc of the problem", path, q.u + 1, q.v + 1);
+        int64_t left = q.flow;
+        for (auto it = lo; it != hi; ++it) { flow[*it] = p->lower[*it]; left -= p->lower[*it]; }
+        for (auto it = lo; it != hi && left > 0; ++it) {
+            const int64_t room = p->upper[*it] - p->lower[*it];
+            const int64_t take = (it + 1 == hi) ? left : std::min(left, room);     // the last arc takes what is left, valid or not
+            flow[*it] += take;
+            left -= take;
+        }
+        if (left < 0) flow[*lo] += left;      // less than the lower bounds: visible to the validator as a bound violation
+    }
+    return MCF_OK;
+}
+
 }  // extern "C"

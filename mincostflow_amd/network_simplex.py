@@ -80,13 +80,38 @@ def read_dimacs(path: str) -> Problem:
     return Problem._take(ps)
 
 
-def write_dimacs(p: Problem, path: str) -> None:
-    src, tgt, lo, up, co, su = _i32(p.source), _i32(p.target), _i64(p.lower), _i64(p.upper), _i64(p.cost), _i64(p.supply)
+def _borrow(p: Problem):
+    """A mcf_problem view of p's arrays (they must stay alive while the struct is in use)."""
+    keep = (_i32(p.source), _i32(p.target), _i64(p.lower), _i64(p.upper), _i64(p.cost), _i64(p.supply))
+    src, tgt, lo, up, co, su = keep
     ps = L.ProblemStruct(p.node_count, p.arc_count, src.ctypes.data_as(C.POINTER(C.c_int32)),
                          tgt.ctypes.data_as(C.POINTER(C.c_int32)), lo.ctypes.data_as(C.POINTER(C.c_int64)),
                          up.ctypes.data_as(C.POINTER(C.c_int64)), co.ctypes.data_as(C.POINTER(C.c_int64)),
                          su.ctypes.data_as(C.POINTER(C.c_int64)))
+    return ps, keep
+
+
+def write_dimacs(p: Problem, path: str) -> None:
+    ps, _keep = _borrow(p)
     L.check(L.lib().mcf_dimacs_write(C.byref(ps), path.encode()))
+
+
+def write_solution(path: str, cost: int, flow, pi=None) -> None:
+    """SolutionLoader.SaveToFile (Loaders/SolutionLoader.cs:186-210)."""
+    flow = _i64(flow)
+    pi = None if pi is None else _i64(pi)
+    L.check(L.lib().mcf_solution_write(path.encode(), int(cost), flow.shape[0], flow.ctypes.data_as(C.c_void_p),
+                                       0 if pi is None else pi.shape[0], None if pi is None else pi.ctypes.data_as(C.c_void_p)))
+
+
+def read_solution(path: str, p: Problem) -> dict:
+    """SolutionLoader.LoadFromFile (:59-176) mapped onto p's arcs: {'cost' (None when the file has no s line), 'flow', 'pi' (None without p lines)}."""
+    ps, _keep = _borrow(p)
+    flow, pi = np.zeros(max(p.arc_count, 1), np.int64), np.zeros(max(p.node_count, 1), np.int64)
+    cost, has_cost, has_pi = C.c_int64(), C.c_int32(), C.c_int32()
+    L.check(L.lib().mcf_solution_read(path.encode(), C.byref(ps), C.byref(cost), C.byref(has_cost), flow.ctypes.data_as(C.c_void_p),
+                                      pi.ctypes.data_as(C.c_void_p), C.byref(has_pi)))
+    return {"cost": cost.value if has_cost.value else None, "flow": flow[: p.arc_count], "pi": pi[: p.node_count] if has_pi.value else None}
 
 
 class NetworkSimplex:

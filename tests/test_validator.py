@@ -176,3 +176,64 @@ def test_validator_at_full_size():
     ref = V.validate(n, src, tgt, lower, upper, cost, supply, V.GEQ, flow, pi, 0)
     _same(dev, ref)
     assert dev["kernel_us"] > 0 and dev["algorithmic_bytes"] == 40 * (n + m)
+
+
+# ------------------------------------------------------------------------------------------------ .sol files (SolutionLoader.cs)
+def _sol_fixtures():
+    import os
+    return [(n, p, w) for n, p, w in fixtures() if os.path.exists(p[:-4] + ".sol")]
+
+
+@pytest.mark.parametrize("name,path,want", _sol_fixtures(), ids=[f[0] for f in _sol_fixtures()])
+def test_bundled_solutions_certify_the_oracle_potentials(name, path, want):
+    """The reference's .sol files hold an independent optimal flow (Gurobi).  Complementary slackness holds between ANY optimal
+    flow and ANY optimal dual, so their flows + the oracle's potentials must pass every check, with objective = dual = the s line."""
+    p = load(path)
+    if p.m > 60000:
+        pytest.skip("covered on the GPU; the CPU suite stays short")
+    g = M.read_dimacs(path)
+    sol = M.read_solution(path[:-4] + ".sol", g)
+    assert sol["cost"] == want and sol["pi"] is None
+    o = O.Oracle(p, O.SEM_CSHARP_OPT, O.RULE_BLOCK)
+    assert o.solve()[0] == O.OPTIMAL
+    r = V.validate(p.n, p.src, p.tgt, p.lower, p.upper, p.cost, p.supply, V.GEQ, sol["flow"], o.potential(), sol["cost"])
+    assert r["valid"] == 1 and r["objective"] == want and r["dual_cost"] == want, r
+
+
+def test_solution_files_round_trip(tmp_path):
+    g = M.Problem(3, 4, np.array([0, 0, 0, 1], np.int32), np.array([1, 1, 2, 2], np.int32), np.array([0, 1, 0, 0], np.int64),
+                  np.array([5, 4, 9, 9], np.int64), np.array([7, 2, 1, 1], np.int64), np.array([6, 0, -6], np.int64))
+    path = str(tmp_path / "a.sol")
+    M.write_solution(path, -12, [0, 3, 0, 4], [0, -2, 5])
+    assert open(path).read().split("\n")[:3] == ["s -12", "f 1 3", "f 3 4"]            # SaveToFile: s line, non-zero flows by arc id
+    r = M.read_solution(path, g)
+    assert r["cost"] == -12 and list(r["flow"]) == [0, 3, 0, 4] and list(r["pi"]) == [0, -2, 5]
+    # end-point format, parallel arcs 0 -> 1: lower bounds first (arc 1 has lower 1), then the cheaper arc (arc 1, cost 2) up to its capacity
+    with open(path, "w") as f:
+        f.write("c Solution file generated from Gurobi output\ns 40\nf 1 2 6\nf 2 3 4\n")
+    r = M.read_solution(path, g)
+    assert r["cost"] == 40 and list(r["flow"]) == [2, 4, 0, 4] and r["pi"] is None
+    with open(path, "w") as f:
+        f.write("f 3 1 2\n")
+    with pytest.raises(M.McfError):
+        M.read_solution(path, g)                                                        # 3 -> 1 is not an arc
+    with open(path, "w") as f:
+        f.write("f 1 2 1\n")
+    r = M.read_solution(path, g)
+    assert r["cost"] is None and list(r["flow"]) == [0, 1, 0, 0]
+    with pytest.raises(M.McfError):
+        M.read_solution(str(tmp_path / "missing.sol"), g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,path,want", _sol_fixtures(), ids=[f[0] for f in _sol_fixtures()])
+def test_bundled_solutions_certify_the_device_potentials(name, path, want):
+    """Same certificate end to end on the device: Gurobi's flow from the .sol file + the potentials of the GPU solve through the
+    device validator."""
+    g = M.read_dimacs(path)
+    sol = M.read_solution(path[:-4] + ".sol", g)
+    ns = M.NetworkSimplex.from_problem(g).set_pivot_rule(M.PivotRule.BestEligible if g.arc_count <= 20000 else M.PivotRule.BlockSearch)
+    assert ns.enable_optimized_pivot(True).solve() == M.SolverStatus.Optimal
+    v = M.SolutionValidator(g.node_count, g.arc_count).upload_network(g.source, g.target, g.lower, g.upper, g.cost, g.supply)
+    r = v.upload_solution(sol["flow"], ns.potentials()).run(V.GEQ, sol["cost"])
+    assert r["valid"] == 1 and r["objective"] == want and r["dual_cost"] == want, r
