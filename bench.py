@@ -362,7 +362,10 @@ def main():
         # throughput mode: several independent instances in flight on ONE GPU (one host thread, stream and resident grid each);
         # the per-pivot host <-> device latency of one solve is hidden behind the others.  Not the headline: solve latency is unchanged.
         import threading
-        cs = [new_solver() for _ in range(args.concurrent)]
+        def shared_solver():
+            ns = M.NetworkSimplex.from_problem(g).set_pivot_rule(rule).enable_optimized_pivot(True)
+            return ns.set_device(local_rank, width, 0, M.ENGINE_SHARE_DEVICE).prepare()
+        cs = [shared_solver() for _ in range(args.concurrent)]
         torch.cuda.synchronize()
         tc = time.perf_counter()
         th = [threading.Thread(target=x.solve) for x in cs]

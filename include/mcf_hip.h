@@ -106,6 +106,9 @@ typedef struct mcf_engine_desc {
                                              list that is complete below a threshold; the following searches are answered on the host
                                              from that list plus the few arcs the pivots touched, whenever that provably is the scan's
                                              answer (identical pivot sequence, fewer round trips).  Off by default. */
+#define MCF_ENGINE_SHARE_DEVICE 64        /* several engines use this device at once (independent solves): keep the resident grid's register
+                                             and LDS footprint small so that their grids are co-resident on every CU -- the grid then gathers
+                                             the potentials for every request instead of keeping them in registers (~0.5 us per search) */
 #define MCF_ENGINE_DISPATCH 16            /* one scan dispatch per search.  Also what an engine falls back to when it is sharded, when
                                              kernel timing flags are set, or when the platform has no host-writable VRAM.
                                              The environment variable MCF_HIP_RESIDENT=0/1 overrides the choice. */

@@ -21,6 +21,7 @@ NOT_SOLVED, OPTIMAL, INFEASIBLE, UNBOUNDED, UNBALANCED = 0, 1, 2, 3, 4
 STATE_UPPER, STATE_TREE, STATE_LOWER = -1, 0, 1
 INF_CAP = np.iinfo(np.int64).max
 ENGINE_SAMPLE_KERNEL_TIME, ENGINE_TIME_EVERY_KERNEL, ENGINE_NO_INLINE_UPDATE, ENGINE_RESIDENT, ENGINE_DISPATCH, ENGINE_CANDIDATES = 1, 2, 4, 8, 16, 32
+ENGINE_SHARE_DEVICE = 64
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OVERFLOW, ERR_TIMEOUT, ERR_STATE, ERR_IO, ERR_COMM = -1, -2, -3, -4, -5, -6, -7, -8
 
 

@@ -89,6 +89,7 @@ struct mcf_engine {
     int grid = 0, unroll = 1;
     bool nt = false;
     bool lds_pi = false;           // node_count <= kLdsPiMax: kernels keep the potentials in LDS
+    bool no_pireg = false;         // MCF_ENGINE_SHARE_DEVICE or MCF_HIP_PIREG=0: the resident grid gathers the potentials for every request
     int lds_grid = 0;
     uint32_t seq = 0;
     bool uploaded = false;
@@ -367,6 +368,8 @@ void launch_resident_r(mcf_engine *e, const ResidentParams<T> &p)
         else hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, false, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
     }
     else if (e->resident_reg && lpi) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, true, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    else if (e->resident_reg && e->res_threads <= kPiRegThreads && !e->no_pireg)
+        hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, false, false, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
     else if (e->resident_reg) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, false, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
     else if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, true, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
     else hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, false, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
@@ -930,6 +933,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
     e->grid = desc->scan_workgroups > 0 ? std::min(desc->scan_workgroups, kMaxWorkgroups) : std::min(groups, max_wg);
     e->grid = std::max(1, std::min(e->grid, groups));
     e->lds_pi = desc->node_count <= kLdsPiMax && !(getenv("MCF_HIP_LDS_PI") && getenv("MCF_HIP_LDS_PI")[0] == '0');
+    e->no_pireg = (desc->flags & MCF_ENGINE_SHARE_DEVICE) || (getenv("MCF_HIP_PIREG") && getenv("MCF_HIP_PIREG")[0] == '0');
     if (e->lds_pi) {
         // one 1024-thread workgroup per CU (the 128 KB potential copy allows no more); each loops over its 4096-arc tiles
         e->unroll = count > (2 << 20) ? 2 : 1;

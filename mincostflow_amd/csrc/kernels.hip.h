@@ -188,16 +188,19 @@ __device__ __forceinline__ void load_tile(const int32_t *src, const int32_t *tgt
     }
 }
 
-template <typename T, int RULE, bool OPT>
-__device__ __forceinline__ void eval_tile(const TileData<T> &d, const T *pi, int e0, int m_s, int next_arc, int block_size, int rstar, Key &best,
-                                          int sub_node = -1, T sub_val = 0)
+// the eight potential gathers of a thread's four arcs
+template <typename T>
+__device__ __forceinline__ void gather_tile(const TileData<T> &d, const T *pi, T ps[4], T pt[4])
 {
-    T ps[4], pt[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { ps[j] = pi[d.s.v[j]]; pt[j] = pi[d.t.v[j]]; }
-    // a single patched potential whose store may still be in flight (resident fast path): take its value from the request
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { ps[j] = d.s.v[j] == sub_node ? sub_val : ps[j]; pt[j] = d.t.v[j] == sub_node ? sub_val : pt[j]; }
+}
+
+// folds the four reduced costs (potentials already in registers) into the running key
+template <typename T, int RULE, bool OPT>
+__device__ __forceinline__ void fold_tile(const TileData<T> &d, const T ps[4], const T pt[4], int e0, int m_s, int next_arc, int block_size, int rstar,
+                                          Key &best)
+{
     uint32_t pos0 = 0;
     if (RULE != MCF_RULE_BEST_ELIGIBLE) {
         int q = e0 - next_arc;
@@ -224,6 +227,18 @@ __device__ __forceinline__ void eval_tile(const TileData<T> &d, const T *pi, int
             }
         }
     }
+}
+
+template <typename T, int RULE, bool OPT>
+__device__ __forceinline__ void eval_tile(const TileData<T> &d, const T *pi, int e0, int m_s, int next_arc, int block_size, int rstar, Key &best,
+                                          int sub_node = -1, T sub_val = 0)
+{
+    T ps[4], pt[4];
+    gather_tile<T>(d, pi, ps, pt);
+    // a single patched potential whose store may still be in flight (resident fast path): take its value from the request
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ps[j] = d.s.v[j] == sub_node ? sub_val : ps[j]; pt[j] = d.t.v[j] == sub_node ? sub_val : pt[j]; }
+    fold_tile<T, RULE, OPT>(d, ps, pt, e0, m_s, next_arc, block_size, rstar, best);
 }
 
 template <typename T, int RULE, bool OPT, bool NT = false>
@@ -491,19 +506,39 @@ __device__ __forceinline__ void publish_candidates(int64_t c1, uint32_t p1, int6
 //               [10..12] potential patch 0 {node, lo, hi}
 //   line 1..    five entries {a, b, c} each: potential patches 1..n_pi-1 {node, lo, hi}, then state patches 2..n_st-1 {arc, value, 0}
 // The poll reads line 0 only (one 64-byte read per workgroup per poll); the other lines are fetched when there are more entries.
-template <typename T, int RULE, bool OPT, bool REG, bool LPI, bool CAND>
-__global__ __launch_bounds__(kResidentThreads) void resident_kernel(const ResidentParams<T> p)
+//
+// PIREG (register-resident arcs, potentials not in LDS, no candidate list, at most kPiRegThreads threads): a thread also keeps the potentials of its arcs' end points in
+// registers and PATCHES them instead of gathering them again for every request -- the eight divergent gathers per thread cost
+// ~1.5 us per request on a CU (one lane per clock) while three out of four pivots move five nodes or fewer.  Lists of up to
+// kPiRegCompare entries are compared against the eight end points directly (LDS broadcast reads); up to one chunk goes through a
+// bitmap in LDS and only the lanes that hit gather again (up to kPiRegBitmapMax entries); longer lists gather everything again.
+constexpr int kPiRegCompare = 20;                 // entries beyond the header patch that are matched by direct comparison (4 lines)
+constexpr int kPiRegBitmapMax = 4096;             // longer lists: most lanes would hit anyway
+constexpr int kPiRegBitmapWords = 4096;           // 131072 bits, indexed by node mod 131072 (aliases only cost a spurious gather)
+
+constexpr int kPiRegThreads = 512;                // PIREG workgroups: at most 8 waves, so a thread may use up to 256 registers (it needs ~170)
+
+template <typename T, int RULE, bool OPT, bool REG, bool LPI, bool CAND, bool PIREG = false>
+__global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resident_kernel(const ResidentParams<T> p)
 {
+    static_assert(!PIREG || (REG && !LPI && !CAND), "PIREG needs register-resident arcs and global potentials");
     // mailbox staging: line 0 + one chunk of patch lines: 16 KB next to LDS-resident potentials, else 32 KB (2555 entries per chunk);
     // kept small so that several resident grids (independent solves) can share a CU
     constexpr int kLines = LPI ? kMailboxLines : 2 * kMailboxLines, kChunk = kLines - 1;
     __shared__ __attribute__((aligned(16))) uint32_t lm[kLines * 16];
     __shared__ __attribute__((aligned(16))) T lpi[LPI ? kLdsPiMax : 2];      // LPI: the whole potential vector lives here
     __shared__ uint32_t s_timeout;
+    __shared__ uint32_t bitmap[PIREG ? kPiRegBitmapWords : 1];
     const int tid = threadIdx.x, nt = (int)blockDim.x;        // 64..1024 threads: the host sizes the grid so that every CU gets a workgroup
     const int my_i0 = blockIdx.x * nt * kArcsPerThread + tid * kArcsPerThread;
     TileData<T> mine;
     if (REG) load_tile<T>(p.src, p.tgt, p.cost, p.state, my_i0, mine);
+    T ps[4], pt[4];                                           // PIREG: pi[source], pi[target] of my four arcs, kept current by the patches
+    if (PIREG) {
+        gather_tile<T>(mine, p.pi, ps, pt);
+        for (int i = tid; i < kPiRegBitmapWords; i += nt) bitmap[i] = 0u;
+        __syncthreads();
+    }
     if (LPI) {
         for (int i = tid; i < p.n_nodes; i += nt) lpi[i] = p.pi[i];
         __syncthreads();
@@ -558,6 +593,8 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
         }
         // ---- patches: final values, applied by EVERY workgroup before it reads (same argument as scan_kernel).
         // The entries beyond the header come in chunks of 255 lines (1275 entries), each line verified by its tag before use.
+        // PIREG: 0 = nothing beyond the header, 1 = compare directly, 2 = bitmap + gather the hits, 3 = gather everything again
+        const int pr_mode = !PIREG ? 0 : (entries == 0 ? 0 : (entries <= kPiRegCompare ? 1 : (entries <= kPiRegBitmapMax ? 2 : 3)));
         bool torn = false;
         for (int first = 1; first < lines; first += kChunk) {
             const int chunk = lines - first < kChunk ? lines - first : kChunk;
@@ -595,9 +632,21 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
                     const int64_t v = (int64_t)(((uint64_t)q[2] << 32) | q[1]);
                     p.pi[q[0]] = (T)v;
                     if (LPI) lpi[q[0]] = (T)v;
+                    if (pr_mode == 2) atomicOr(&bitmap[(q[0] >> 5) & (kPiRegBitmapWords - 1)], 1u << (q[0] & 31));
                 } else {
                     const int a = (int)q[0] - p.base;
                     if ((unsigned)a < (unsigned)p.count_padded) p.state[a] = (int8_t)q[1];
+                }
+            }
+            if (pr_mode == 1) {                             // every thread matches the chunk's potential patches against its eight end points
+                const int hi_pi = i_hi < extra_pi ? i_hi : extra_pi;
+                for (int i = i_lo; i < hi_pi; ++i) {
+                    const int rel = i - i_lo;
+                    const uint32_t *q = lm + (1 + rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
+                    const int node = (int)q[0];
+                    const T v = (T)(int64_t)(((uint64_t)q[2] << 32) | q[1]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { ps[j] = mine.s.v[j] == node ? v : ps[j]; pt[j] = mine.t.v[j] == node ? v : pt[j]; }
                 }
             }
             if (REG && extra_st > 0) {                      // every thread checks the chunk's state patches against its four arcs
@@ -614,7 +663,7 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
         if (torn) continue;                                // a line was still in flight: poll again (re-applying final values is harmless)
         // header patches.  With nothing but them (n_pi <= 1, n_st <= 2) and register-resident arcs nobody has to wait for the stores:
         // the potential is substituted from the request while its store retires behind the scan.
-        const bool fast = REG && entries == 0;
+        const bool fast = REG && (entries == 0 || pr_mode == 1);
         const T v0 = (T)(int64_t)(((uint64_t)p0_hi << 32) | p0_lo);
         if (n_pi | n_st) {
             if (tid == 0 && n_pi > 0) { p.pi[p0_node] = v0; if (LPI) lpi[p0_node] = v0; }
@@ -630,6 +679,24 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
             }
         }
         const int sub_node = (fast && n_pi > 0) ? (int)p0_node : -1;
+        if (PIREG) {
+            if (pr_mode == 2) {                            // the stores have retired (barrier above): lanes whose end points are on the list gather again
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t a = (uint32_t)mine.s.v[j], b = (uint32_t)mine.t.v[j];
+                    if ((bitmap[(a >> 5) & (kPiRegBitmapWords - 1)] >> (a & 31)) & 1u) ps[j] = p.pi[a];
+                    if ((bitmap[(b >> 5) & (kPiRegBitmapWords - 1)] >> (b & 31)) & 1u) pt[j] = p.pi[b];
+                }
+                __syncthreads();                           // everybody has tested before the bitmap is wiped
+                for (int i = tid; i < kPiRegBitmapWords; i += nt) bitmap[i] = 0u;
+            } else if (pr_mode == 3) {
+                gather_tile<T>(mine, p.pi, ps, pt);
+            }
+            if (n_pi > 0) {                                // the header patch is on no list
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ps[j] = mine.s.v[j] == (int)p0_node ? v0 : ps[j]; pt[j] = mine.t.v[j] == (int)p0_node ? v0 : pt[j]; }
+            }
+        }
         // ---- scan
         if (CAND) {
             int64_t c1, c2;
@@ -641,7 +708,9 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
             best.c = 0;
             best.r = kNone;
             best.p = kNone;
-            if (REG) {
+            if (PIREG) {
+                fold_tile<T, RULE, OPT>(mine, ps, pt, p.base + my_i0, p.m_s, next_arc, p.block_size, rstar, best);
+            } else if (REG) {
                 eval_tile<T, RULE, OPT>(mine, pi_view, p.base + my_i0, p.m_s, next_arc, p.block_size, rstar, best, sub_node, v0);
             } else {
                 for (int i0 = my_i0; i0 < p.count_padded; i0 += gridDim.x * nt * kArcsPerThread) {
@@ -656,7 +725,7 @@ __global__ __launch_bounds__(kResidentThreads) void resident_kernel(const Reside
         served += 1;
         idle_since = __builtin_amdgcn_s_memrealtime();
         scan_ticks += idle_since - t_seen;
-        if (fast && tid < 3) __builtin_amdgcn_s_waitcnt(0);   // the header patches' stores have retired before anybody gathers again
+        if (fast) __builtin_amdgcn_s_waitcnt(0);           // the patches' stores have retired before anybody gathers again
         __syncthreads();                                   // lm and the reduction scratch are reused by the next request
     }
 }

@@ -30,7 +30,8 @@ def _oracle_scan(rule, optimized, a, m_s, block, next_arc):
     return O.scan_block(m_s, a["state"], a["cost"], a["src"], a["tgt"], a["pi"], block, optimized, next_arc)
 
 
-MODES = [pytest.param(0, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"), pytest.param(M.ENGINE_CANDIDATES, id="candidates")]
+MODES = [pytest.param(0, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"), pytest.param(M.ENGINE_CANDIDATES, id="candidates"),
+         pytest.param(M.ENGINE_SHARE_DEVICE, id="resident-shared")]      # resident grid without register-resident potentials
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -41,7 +42,9 @@ def test_scan_matches_oracle_on_random_arrays(width, rule, optimized, mode):
     engine modes: the resident grid fed through the mailbox and one dispatch per search."""
     rng = np.random.default_rng(1234 + width + 10 * rule + optimized)
     for m_s, n, span in [(1, 2, 3), (3, 2, 2), (4, 5, 2), (5, 3, 50), (1023, 40, 3), (1024, 300, 2), (1025, 7, 10 ** 6),
-                         (4097, 5000, 4), (100003, 20000, 10 ** 4), (2 ** 20 + 5, 3000, 10 ** 5)]:
+                         (4097, 5000, 4), (100003, 20000, 10 ** 4), (2 ** 20 + 5, 3000, 10 ** 5),
+                         # potentials too many for LDS: register-resident potentials (<= 512 threads per workgroup) and, at 600k arcs, without
+                         (50001, 17000, 3), (400003, 100001, 10 ** 4), (600000, 50000, 5)]:
         pi_span = 10 ** 9 if width == 64 and span > 100 else span * 3
         a = _random_soa(rng, m_s, n, span, pi_span)
         block = int(rng.integers(1, max(2, min(m_s, 700))))
@@ -63,7 +66,7 @@ def test_scan_matches_oracle_on_random_arrays(width, rule, optimized, mode):
             vals = rng.integers(-1, 2, len(arcs)).astype(np.int8)
             a["state"][arcs] = vals
             eng.patch_state(arcs, vals)
-            k = int(rng.choice([0, 1, 5, 96, 97, min(n, 3000)]))
+            k = int(rng.choice([0, 1, 5, 20, 21, 22, 96, 97, min(n, 3000), 4097, 4098, 6000]))   # every patch path of the resident grid
             k = min(k, n)
             nodes = rng.choice(n, size=k, replace=False).astype(np.int32)
             sigma = int(rng.integers(-span - 1, span + 2))
