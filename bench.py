@@ -285,7 +285,7 @@ def main():
         avg_launch_ns = kernel_ns / max(launches, 1)
         achieved = bytes_per_launch / avg_launch_ns if avg_launch_ns > 0 else 0.0       # bytes/ns == GB/s
         in_kernel_ns = sum(x["resident_scan_ns"] for x in e) / max(requests, 1)
-        kernel_name = "resident_kernel<int64, BestEligible, REG>"
+        kernel_name = "resident_kernel<int64, BestEligible, REG, PIREG>" if mets[0]["engine"]["scan_threads"] <= 512 else "resident_kernel<int64, BestEligible, REG>"
         extra = {"launches": launches, "requests_per_launch": requests / max(launches, 1), "avg_launch_ms": avg_launch_ns / 1e6,
                  "in_kernel": {"avg_request_us": in_kernel_ns / 1e3, "achieved": bytes_per_scan / in_kernel_ns if in_kernel_ns > 0 else 0.0,
                                "frac": bytes_per_scan / in_kernel_ns / HBM_PEAK_GBS if in_kernel_ns > 0 else 0.0,
