@@ -106,7 +106,11 @@ def microbench():
                     "warm_us": warm[0] / 1e3, "cold_us": cold[0] / 1e3, "warm_GBs": nbytes / warm[0], "cold_GBs": nbytes / cold[0],
                     "warm_frac_of_hbm_peak": nbytes / warm[0] / HBM_PEAK_GBS, "cold_frac_of_hbm_peak": nbytes / cold[0] / HBM_PEAK_GBS})
 
-    for label, m_s, n in (("dense (assignment-like), potentials fit LDS", 64_000_000, 2_001),
+    # SURVEY.md 8d sizes: m_s in {4e5, 1e6, 8e6, 6.4e7}, uniform random arrays
+    for label, m_s, n in (("config-3 size, uniform random end points", 400_000, 100_001),
+                          ("1M arcs, uniform random end points over 125k nodes", 1_000_000, 125_001),
+                          ("8M arcs, uniform random end points over 1M nodes", 8_000_000, 1_000_001),
+                          ("dense (assignment-like), potentials fit LDS", 64_000_000, 2_001),
                           ("uniform random end points over 1M nodes (gather worst case)", 64_000_000, 1_000_001)):
         run(label, n, m_s, rng.integers(0, n, m_s, dtype=np.int32), rng.integers(0, n, m_s, dtype=np.int32),
             rng.integers(-10 ** 4, 10 ** 4, m_s, dtype=np.int64), rng.integers(-1, 2, m_s, dtype=np.int8),
@@ -120,6 +124,25 @@ def microbench():
     run("NETGEN-like 1M nodes / 8M arcs start basis (config 5 arrays)", g5.node_count + 1, ms, it["source"][:ms], it["target"][:ms],
         it["cost"][:ms], it["state"][:ms], it["pi"], "generator order: grouped by tail, random heads")
     return out
+
+
+def hbm_probe():
+    """What this box's HBM delivers to a plain device-to-device copy (read + write), beside the nominal 8 TB/s used as `peak`."""
+    import torch
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device="cuda"); b = torch.empty_like(a)
+    a.fill_(1)
+    for _ in range(3):
+        b.copy_(a)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    reps = 10
+    for _ in range(reps):
+        b.copy_(a)
+    ev1.record(); torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / reps
+    del a, b
+    return {"what": "torch device-to-device copy of 1 GiB (bytes read + bytes written) / time", "GBps": 2 * n / ms / 1e6, "ms": ms}
 
 
 def validator_bench(M, g, ns, local_rank, with_cpu):
@@ -385,6 +408,7 @@ def main():
             line["cpu_baseline_block_search"] = blk       # the reference's default rule, for the cross-rule comparison
     if not args.no_microbench and args.gpus == 1:
         line["scan_microbench"] = microbench()
+        line["hbm_measured"] = hbm_probe()
     if not args.no_validator and args.gpus == 1:
         line["solution_validator"] = validator_bench(M, g, solvers[0], local_rank, not args.no_cpu_baseline)
     print(json.dumps(line))
