@@ -89,6 +89,11 @@ struct mcf_engine {
     int grid = 0, unroll = 1;
     bool nt = false;
     bool lds_pi = false;           // node_count <= kLdsPiMax: kernels keep the potentials in LDS
+    // bucketed layout (Best Eligible, potentials neither in LDS nor next to register-resident arcs, large sparse instances): the arcs are
+    // stored stably sorted by target-node range so that one range's potentials (1 MB) stay in every XCD's L2 while the grid sweeps it
+    int bucket_nodes = 0;          // nodes per range; 0 = arcs are stored in their own order
+    std::vector<int32_t> pos_of;   // local arc -> local position (identity when bucket_nodes == 0: empty)
+    int32_t *d_orig = nullptr;     // local position -> global arc id
     bool no_pireg = false;         // MCF_ENGINE_SHARE_DEVICE or MCF_HIP_PIREG=0: the resident grid gathers the potentials for every request
     int lds_grid = 0;
     uint32_t seq = 0;
@@ -180,6 +185,7 @@ void fill_params(mcf_engine *e, ScanParams<T> &p, bool with_patches)
     p.state = e->d_state;
     p.pi = (T *)e->d_pi;
     p.slots = e->d_slots;
+    p.orig = e->bucket_nodes > 0 ? e->d_orig : nullptr;
     p.base = e->begin;
     p.count_padded = e->count_padded;
     p.m_s = e->d.search_arc_num;
@@ -206,6 +212,13 @@ template <typename T, int RULE, bool OPT, int UNROLL, bool NT>
 void launch_scan_k(mcf_engine *e, const ScanParams<T> &p, hipEvent_t start, hipEvent_t stop)
 {
     const dim3 grid(e->grid), block(kThreads);
+    if constexpr (RULE == MCF_RULE_BEST_ELIGIBLE) {
+        if (e->bucket_nodes > 0) {
+            if (start) hipExtLaunchKernelGGL((scan_kernel<T, RULE, OPT, UNROLL, NT, true>), grid, block, 0, e->stream, start, stop, 0, p);
+            else hipLaunchKernelGGL((scan_kernel<T, RULE, OPT, UNROLL, NT, true>), grid, block, 0, e->stream, p);
+            return;
+        }
+    }
     if (start) hipExtLaunchKernelGGL((scan_kernel<T, RULE, OPT, UNROLL, NT>), grid, block, 0, e->stream, start, stop, 0, p);
     else hipLaunchKernelGGL((scan_kernel<T, RULE, OPT, UNROLL, NT>), grid, block, 0, e->stream, p);
 }
@@ -355,6 +368,8 @@ uint32_t *alloc_bar_vram(int hip_device, size_t bytes)
     return (uint32_t *)ptr;
 }
 
+constexpr int kBucketNodes = 131072;        // 1 MB of int64 potentials per range: measured best on config 5 (profiles/r01_bucketed_layout_feasibility.txt)
+constexpr int kBucketMinArcs = 2 << 20;
 constexpr int kResidentMaxGrid = 256;       // one workgroup (64..1024 threads) per CU: always co-resident, every CU gathers
 constexpr uint32_t kResidentIdleTicks = 25000000u;   // 0.25 s of s_memrealtime
 
@@ -372,7 +387,15 @@ void launch_resident_r(mcf_engine *e, const ResidentParams<T> &p)
         hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, false, false, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
     else if (e->resident_reg) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, false, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
     else if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, true, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
-    else hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, false, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    else {
+        if constexpr (RULE == MCF_RULE_BEST_ELIGIBLE) {
+            if (e->bucket_nodes > 0) {
+                hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, false, false, false, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+                return;
+            }
+        }
+        hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, false, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    }
 }
 
 template <typename T>
@@ -380,7 +403,7 @@ int launch_resident(mcf_engine *e, uint32_t start_seq)
 {
     ResidentParams<T> p;
     p.src = e->d_src; p.tgt = e->d_tgt; p.cost = (const T *)e->d_cost; p.state = e->d_state; p.pi = (T *)e->d_pi;
-    p.slots = e->d_slots; p.mailbox = e->mailbox; p.exit_word = e->d_exit;
+    p.slots = e->d_slots; p.orig = e->bucket_nodes > 0 ? e->d_orig : nullptr; p.mailbox = e->mailbox; p.exit_word = e->d_exit;
     p.base = e->begin; p.count_padded = e->count_padded; p.m_s = e->d.search_arc_num; p.block_size = e->block_size;
     p.start_seq = start_seq; p.idle_ticks = kResidentIdleTicks; p.n_nodes = e->d.node_count; p.max_pi = e->patch_capacity; p.max_st = e->mailbox_max_st; p.poll_replicas = e->poll_replicas; p.poll_sleep = e->poll_sleep;
     const bool opt = e->d.semantics == MCF_SEM_OPTIMIZED;
@@ -1002,6 +1025,15 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         }
     }
     e->st.scan_workgroups = e->resident_ok ? e->res_grid : e->grid;
+    {
+        // bucketed layout: automatic for large sparse Best-Eligible instances; MCF_HIP_BUCKET_NODES=N forces N nodes per range (0 = off)
+        int want = (count >= kBucketMinArcs && desc->node_count > 2 * kBucketNodes) ? kBucketNodes : 0;
+        if (const char *u = getenv("MCF_HIP_BUCKET_NODES")) want = std::max(0, atoi(u));
+        const bool tile_loop = !e->lds_pi && !(e->resident_ok && e->resident_reg);
+        if (want > 0 && desc->rule == MCF_RULE_BEST_ELIGIBLE && tile_loop && !e->cand_on) {
+            if (hipMalloc((void **)&e->d_orig, sizeof(int32_t) * e->count_padded) == hipSuccess) e->bucket_nodes = want;
+        }
+    }
     e->st.scan_threads = e->resident_ok ? e->res_threads : (e->lds_pi ? kResidentThreads : kThreads);
     e->st.resident = e->resident_ok ? 1 : 0;
     e->st.candidates = e->cand_on ? 1 : 0;
@@ -1021,6 +1053,7 @@ void mcf_engine_destroy(mcf_engine *e)
     if (e->res_start) (void)hipEventDestroy(e->res_start);
     if (e->res_stop) (void)hipEventDestroy(e->res_stop);
     if (e->comm && rccl() && rccl()->comm_destroy) rccl()->comm_destroy(e->comm);
+    if (e->d_orig) (void)hipFree(e->d_orig);
     (void)hipFree(e->d_src); (void)hipFree(e->d_tgt); (void)hipFree(e->d_cost); (void)hipFree(e->d_state); (void)hipFree(e->d_pi);
     (void)hipFree(e->d_cand_local); (void)hipFree(e->d_cand_all); (void)hipFree(e->d_flush);
     if (e->h_cand_all) (void)hipHostFree(e->h_cand_all);
@@ -1054,9 +1087,25 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
     e->max_abs_cost = maxc;
     std::vector<int32_t> s(cp, 0), t(cp, 0);
     std::vector<int8_t> st(cp, 0);
-    memcpy(s.data(), source + e->begin, sizeof(int32_t) * count);
-    memcpy(t.data(), target + e->begin, sizeof(int32_t) * count);
-    memcpy(st.data(), state + e->begin, count);
+    const int32_t *pos = nullptr;                      // local arc -> local position
+    if (e->bucket_nodes > 0) {
+        // stable counting sort by target range: inside a range the arcs keep their order (sources stay grouped, ties resolve by position)
+        const int buckets = (n + e->bucket_nodes - 1) / e->bucket_nodes;
+        std::vector<int32_t> start(buckets + 1, 0);
+        for (int i = 0; i < count; ++i) start[target[e->begin + i] / e->bucket_nodes + 1]++;
+        for (int b = 0; b < buckets; ++b) start[b + 1] += start[b];
+        e->pos_of.resize(count);
+        std::vector<int32_t> orig(cp, 0x7FFFFFFF);
+        for (int i = 0; i < count; ++i) {
+            const int q = start[target[e->begin + i] / e->bucket_nodes]++;
+            e->pos_of[i] = q;
+            orig[q] = e->begin + i;
+        }
+        pos = e->pos_of.data();
+        HIP_TRY(hipMemcpy(e->d_orig, orig.data(), sizeof(int32_t) * cp, hipMemcpyHostToDevice));
+    }
+    auto at = [&](int i) { return pos ? pos[i] : i; };
+    for (int i = 0; i < count; ++i) { const int q = at(i); s[q] = source[e->begin + i]; t[q] = target[e->begin + i]; st[q] = state[e->begin + i]; }
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->d_src, s.data(), sizeof(int32_t) * cp, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_tgt, t.data(), sizeof(int32_t) * cp, hipMemcpyHostToDevice));
@@ -1066,7 +1115,7 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
         std::vector<int32_t> c(cp, 0), p(n);
         for (int i = 0; i < count; ++i) {
             if (!fits32(cost[e->begin + i])) return mcf::fail(MCF_ERR_OVERFLOW, "cost of arc %d does not fit int32", e->begin + i);
-            c[i] = (int32_t)cost[e->begin + i];
+            c[at(i)] = (int32_t)cost[e->begin + i];
         }
         for (int i = 0; i < n; ++i) {
             if (!fits32(pi[i])) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d does not fit int32", i);
@@ -1076,7 +1125,7 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
         HIP_TRY(hipMemcpy(e->d_pi, p.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
     } else {
         std::vector<int64_t> c(cp, 0);
-        memcpy(c.data(), cost + e->begin, sizeof(int64_t) * count);
+        for (int i = 0; i < count; ++i) c[at(i)] = cost[e->begin + i];
         HIP_TRY(hipMemcpy(e->d_cost, c.data(), sizeof(int64_t) * cp, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(e->d_pi, pi, sizeof(int64_t) * n, hipMemcpyHostToDevice));
     }
@@ -1118,12 +1167,15 @@ int mcf_engine_patch_state(mcf_engine *e, int32_t count, const int32_t *arcs, co
         if (states[i] < -1 || states[i] > 1) return mcf::fail(MCF_ERR_INVALID, "state %d is not -1/0/1", states[i]);
         if (arcs[i] < e->begin || arcs[i] >= e->end) continue;   // not resident here (outside the search range or another shard)
         if (e->cand_on) { e->h_state[arcs[i]] = states[i]; cand_touch_arc(e, arcs[i]); continue; }
+        // the device addresses state[] by position: begin + position of the arc in the stored order
+        if (e->bucket_nodes > 0 && e->pos_of.empty()) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
+        const int32_t where = e->bucket_nodes > 0 ? e->begin + e->pos_of[arcs[i] - e->begin] : arcs[i];
         bool dup = false;
         for (size_t j = 0; j < e->pend_arc.size(); ++j)
-            if (e->pend_arc[j] == arcs[i]) { e->pend_state[j] = states[i]; dup = true; }
+            if (e->pend_arc[j] == where) { e->pend_state[j] = states[i]; dup = true; }
         if (dup) continue;
         if ((int)e->pend_arc.size() >= 64) { int rc = flush_pending(e); if (rc) return rc; }
-        e->pend_arc.push_back(arcs[i]);
+        e->pend_arc.push_back(where);
         e->pend_state.push_back(states[i]);
     }
     return MCF_OK;
@@ -1216,7 +1268,8 @@ int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, con
         if (a < 0 || a >= e->d.arc_capacity) return mcf::fail(MCF_ERR_INVALID, "arc %d out of range", a);
         if ((unsigned)source[i] >= (unsigned)e->d.node_count || (unsigned)target[i] >= (unsigned)e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "arc %d: end point out of range", a);
         if (a < e->begin || a >= e->end) continue;
-        const int l = a - e->begin;
+        if (e->bucket_nodes > 0 && e->pos_of.empty()) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
+        const int l = e->bucket_nodes > 0 ? e->pos_of[a - e->begin] : a - e->begin;     // the arc keeps its position even if its target leaves the range
         if (e->cand_on) return mcf::fail(MCF_ERR_STATE, "mcf_engine_patch_arcs is not available with MCF_ENGINE_CANDIDATES (upload again)");
         HIP_TRY(hipMemcpy(e->d_src + l, &source[i], 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(e->d_tgt + l, &target[i], 4, hipMemcpyHostToDevice));
@@ -1321,6 +1374,12 @@ int mcf_engine_download_state(mcf_engine *e, int8_t *out)
     if (!rc) rc = flush_pending(e);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->bucket_nodes > 0) {
+        std::vector<int8_t> stored(e->end - e->begin);
+        HIP_TRY(hipMemcpy(stored.data(), e->d_state, stored.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < e->end - e->begin; ++i) out[e->begin + i] = stored[e->pos_of[i]];
+        return MCF_OK;
+    }
     HIP_TRY(hipMemcpy(out + e->begin, e->d_state, e->end - e->begin, hipMemcpyDeviceToHost));
     return MCF_OK;
 }

@@ -59,6 +59,7 @@ struct ScanParams {
     int8_t *state;
     T *pi;
     Slot *slots;
+    const int32_t *orig;   // bucketed layout: global arc id of every local position (nullptr = arcs are stored in their own order)
     int32_t base;          // global index of local arc 0
     int32_t count_padded;  // local arcs incl. padding (multiple of kPad)
     int32_t m_s;           // global search_arc_num
@@ -197,9 +198,12 @@ __device__ __forceinline__ void gather_tile(const TileData<T> &d, const T *pi, T
 }
 
 // folds the four reduced costs (potentials already in registers) into the running key
-template <typename T, int RULE, bool OPT>
+// PERM (Best Eligible only): the arcs are stored in a bucketed order (engine.hip: build_layout) and e0 counts POSITIONS; orig[position - base]
+// is the arc's id, which is what breaks ties (NS.cs:1653: lowest arc index among equal reduced costs).  Positions keep the arcs' own
+// order inside a bucket, so only a tie with the running best costs the two look-ups.
+template <typename T, int RULE, bool OPT, bool PERM = false>
 __device__ __forceinline__ void fold_tile(const TileData<T> &d, const T ps[4], const T pt[4], int e0, int m_s, int next_arc, int block_size, int rstar,
-                                          Key &best)
+                                          Key &best, const int32_t *orig = nullptr, int base = 0)
 {
     uint32_t pos0 = 0;
     if (RULE != MCF_RULE_BEST_ELIGIBLE) {
@@ -215,6 +219,7 @@ __device__ __forceinline__ void fold_tile(const TileData<T> &d, const T ps[4], c
         const int64_t rc = st > 0 ? dd : (st < 0 ? -dd : 0);
         if (RULE == MCF_RULE_BEST_ELIGIBLE) {
             if (rc < best.c) { best.c = rc; best.p = (uint32_t)(e0 + j); }   // strict <: lowest arc wins ties
+            else if (PERM && rc == best.c && rc < 0 && orig[e0 + j - base] < orig[(int)best.p - base]) best.p = (uint32_t)(e0 + j);
         } else {
             uint32_t pos = pos0 + j;   // the group may straddle the wrap point
             if (pos >= (uint32_t)m_s) pos -= (uint32_t)m_s;
@@ -229,24 +234,24 @@ __device__ __forceinline__ void fold_tile(const TileData<T> &d, const T ps[4], c
     }
 }
 
-template <typename T, int RULE, bool OPT>
+template <typename T, int RULE, bool OPT, bool PERM = false>
 __device__ __forceinline__ void eval_tile(const TileData<T> &d, const T *pi, int e0, int m_s, int next_arc, int block_size, int rstar, Key &best,
-                                          int sub_node = -1, T sub_val = 0)
+                                          int sub_node = -1, T sub_val = 0, const int32_t *orig = nullptr, int base = 0)
 {
     T ps[4], pt[4];
     gather_tile<T>(d, pi, ps, pt);
     // a single patched potential whose store may still be in flight (resident fast path): take its value from the request
 #pragma unroll
     for (int j = 0; j < 4; ++j) { ps[j] = d.s.v[j] == sub_node ? sub_val : ps[j]; pt[j] = d.t.v[j] == sub_node ? sub_val : pt[j]; }
-    fold_tile<T, RULE, OPT>(d, ps, pt, e0, m_s, next_arc, block_size, rstar, best);
+    fold_tile<T, RULE, OPT, PERM>(d, ps, pt, e0, m_s, next_arc, block_size, rstar, best, orig, base);
 }
 
-template <typename T, int RULE, bool OPT, bool NT = false>
+template <typename T, int RULE, bool OPT, bool NT = false, bool PERM = false>
 __device__ __forceinline__ void scan_tile(const ScanParams<T> &p, int i0, Key &best)
 {
     TileData<T> d;
     load_tile<T, NT>(p.src, p.tgt, p.cost, p.state, i0, d);
-    eval_tile<T, RULE, OPT>(d, p.pi, p.base + i0, p.m_s, p.next_arc, p.block_size, p.rstar, best);
+    eval_tile<T, RULE, OPT, PERM>(d, p.pi, p.base + i0, p.m_s, p.next_arc, p.block_size, p.rstar, best, -1, (T)0, p.orig, p.base);
 }
 
 // workgroup-level finish: wave butterfly -> LDS -> one 16-byte record.  SYSTEM = write-through store for kernels that keep running.
@@ -277,9 +282,10 @@ __device__ __forceinline__ void publish_best(Key best, Slot *slot, uint32_t tag,
     }
 }
 
-template <typename T, int RULE, bool OPT, int UNROLL, bool NT = false>
+template <typename T, int RULE, bool OPT, int UNROLL, bool NT = false, bool PERM = false>
 __global__ __launch_bounds__(kThreads) void scan_kernel(const ScanParams<T> p)
 {
+    static_assert(!PERM || RULE == MCF_RULE_BEST_ELIGIBLE, "the bucketed layout serves Best Eligible only");
     const int tid = threadIdx.x;
     // ---- inline patches of the previous pivot: final values, applied by EVERY workgroup before it reads
     if (p.n_pi | p.n_st) {
@@ -300,8 +306,9 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(const ScanParams<T> p)
     const int step = gridDim.x * kTile * UNROLL;
     for (int i0 = blockIdx.x * kTile * UNROLL + tid * kArcsPerThread; i0 < p.count_padded; i0 += step) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) scan_tile<T, RULE, OPT, NT>(p, i0 + u * kTile, best);
+        for (int u = 0; u < UNROLL; ++u) scan_tile<T, RULE, OPT, NT, PERM>(p, i0 + u * kTile, best);
     }
+    if (PERM && best.p != kNone) best.p = (uint32_t)p.orig[(int)best.p - p.base];     // position -> arc id; from here on everything is as without PERM
     publish_best<RULE, false>(best, p.slots + (size_t)blockIdx.x * kSlotStride, p.seq, true);
 }
 
@@ -361,6 +368,7 @@ struct ResidentParams {
     int8_t *state;
     T *pi;
     Slot *slots;
+    const int32_t *orig;        // bucketed layout (see ScanParams), only read by the PERM variant
     const uint32_t *mailbox;    // fine-grained VRAM, written by the host through the BAR
     uint32_t *exit_word;        // pinned host memory: [0] exit code, [1] requests served, [2..3] scan ticks of workgroup 0
     int32_t base, count_padded, m_s, block_size;
@@ -518,9 +526,10 @@ constexpr int kPiRegBitmapWords = 4096;           // 131072 bits, indexed by nod
 
 constexpr int kPiRegThreads = 512;                // PIREG workgroups: at most 8 waves, so a thread may use up to 256 registers (it needs ~170)
 
-template <typename T, int RULE, bool OPT, bool REG, bool LPI, bool CAND, bool PIREG = false>
+template <typename T, int RULE, bool OPT, bool REG, bool LPI, bool CAND, bool PIREG = false, bool PERM = false>
 __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resident_kernel(const ResidentParams<T> p)
 {
+    static_assert(!PERM || (RULE == MCF_RULE_BEST_ELIGIBLE && !REG && !LPI && !CAND), "the bucketed layout serves the tile loop of Best Eligible");
     static_assert(!PIREG || (REG && !LPI && !CAND), "PIREG needs register-resident arcs and global potentials");
     // mailbox staging: line 0 + one chunk of patch lines: 16 KB next to LDS-resident potentials, else 32 KB (2555 entries per chunk);
     // kept small so that several resident grids (independent solves) can share a CU
@@ -716,8 +725,9 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
                 for (int i0 = my_i0; i0 < p.count_padded; i0 += gridDim.x * nt * kArcsPerThread) {
                     TileData<T> d;
                     load_tile<T>(p.src, p.tgt, p.cost, p.state, i0, d);
-                    eval_tile<T, RULE, OPT>(d, pi_view, p.base + i0, p.m_s, next_arc, p.block_size, rstar, best);
+                    eval_tile<T, RULE, OPT, PERM>(d, pi_view, p.base + i0, p.m_s, next_arc, p.block_size, rstar, best, -1, (T)0, p.orig, p.base);
                 }
+                if (PERM && best.p != kNone) best.p = (uint32_t)p.orig[(int)best.p - p.base];
             }
             publish_best<RULE, true, kResidentThreads>(best, p.slots + (size_t)blockIdx.x * kSlotStride, seq, true);
         }

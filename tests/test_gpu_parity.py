@@ -445,3 +445,42 @@ def test_random_small_networks_all_outcomes(seed):
             assert len(ns.trace()) == len(tr_o) and ns.get_total_cost() == o.total_cost
             assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
     assert seen       # at least something ran
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [pytest.param(M.ENGINE_DISPATCH, id="dispatch"), pytest.param(0, id="resident")])
+@pytest.mark.parametrize("bucket", [700, 4096])
+def test_bucketed_layout_keeps_every_tie_break(mode, bucket, monkeypatch):
+    """Arcs stored sorted by target-node range (MCF_HIP_BUCKET_NODES forces it on small inputs): same arc, same reduced cost, same state
+    and potentials as the oracle, with tiny cost ranges so that ties between arcs of different ranges decide most searches."""
+    monkeypatch.setenv("MCF_HIP_BUCKET_NODES", str(bucket))
+    rng = np.random.default_rng(77 + bucket)
+    for m_s, n, span, width in [(50001, 17000, 2, 64), (400003, 100001, 3, 64), (300000, 20000, 10 ** 4, 32), (1_300_000, 30000, 2, 64)]:
+        a = _random_soa(rng, m_s, n, span, span * 3)
+        eng = M.PivotEngine(n, len(a["src"]), m_s, rule=M.PivotRule.BestEligible, optimized=True, int_width=width, flags=mode)
+        eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+        for it in range(10):
+            f, e, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+            f2, e2, c2 = eng.find_entering()
+            assert f2 == f and (not f or (e2, c2) == (e, c)), (m_s, it, e2, e, c2, c)
+            arcs = rng.choice(m_s, size=int(rng.integers(0, 3)), replace=False).astype(np.int32)
+            vals = rng.integers(-1, 2, len(arcs)).astype(np.int8)
+            a["state"][arcs] = vals
+            eng.patch_state(arcs, vals)
+            k = int(rng.choice([0, 1, 5, 97, 3000]))
+            nodes = rng.choice(n, size=k, replace=False).astype(np.int32)
+            sigma = int(rng.integers(-span - 1, span + 2))
+            a["pi"][nodes] += sigma
+            eng.update_potential(nodes, sigma)
+        assert np.array_equal(eng.download_pi(), a["pi"])
+        assert np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
+
+
+@pytest.mark.gpu
+def test_bucketed_layout_solves_pivot_for_pivot(monkeypatch):
+    monkeypatch.setenv("MCF_HIP_BUCKET_NODES", "2048")
+    p = load("netgen_8_14a")           # 16384 nodes: the potentials do not fit LDS, so the tile loop (and with it the bucketed layout) is used
+    for flags in (M.ENGINE_DISPATCH,):
+        o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, O.RULE_BEST, flags=flags)
+        assert st == st_o == O.OPTIMAL and np.array_equal(ns.trace(), tr_o)
+        assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
