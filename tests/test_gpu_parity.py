@@ -484,3 +484,35 @@ def test_bucketed_layout_solves_pivot_for_pivot(monkeypatch):
         o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, O.RULE_BEST, flags=flags)
         assert st == st_o == O.OPTIMAL and np.array_equal(ns.trace(), tr_o)
         assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
+
+
+@pytest.mark.gpu
+def test_bucketed_layout_on_arc_shards(monkeypatch):
+    """Every shard stores ITS arcs in bucketed order (positions are shard-local, ids global): the resolved answer is still the oracle's."""
+    monkeypatch.setenv("MCF_HIP_BUCKET_NODES", "900")
+    rng = np.random.default_rng(4242)
+    m_s, n, world = 200003, 20000, 3
+    a = _random_soa(rng, m_s, n, 2, 6, extra=0)
+    shards = []
+    for r in range(world):
+        e = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible, optimized=True, shard=M.shard_range(m_s, r, world))
+        e.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+        shards.append(e)
+    for it in range(10):
+        f, arc, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+        cands = [e.find_entering_local() for e in shards]
+        got = [e.resolve(cands) for e in shards]
+        assert all(g[0] == f and (not f or (g[1], g[2]) == (arc, c)) for g in got), (it, got, arc, c)
+        arcs = rng.choice(m_s, size=3, replace=False).astype(np.int32); vals = rng.integers(-1, 2, 3).astype(np.int8)
+        a["state"][arcs] = vals
+        nodes = rng.choice(n, size=int(rng.choice([1, 40, 500])), replace=False).astype(np.int32)
+        a["pi"][nodes] -= 2
+        for e in shards:
+            e.patch_state(arcs, vals)
+            e.update_potential(nodes, -2)
+    full = np.zeros(m_s, np.int8)
+    for e in shards:
+        st = e.download_state()
+        b, en = M.shard_range(m_s, shards.index(e), world)
+        full[b:en] = st[b:en]
+    assert np.array_equal(full, a["state"][:m_s])
