@@ -126,6 +126,25 @@ def microbench():
     return out
 
 
+def large_instance_sample(M, local_rank, with_cpu, gpu_pivots=3000, cpu_seconds=4.0):
+    """BASELINE.json configs[4] on ONE GPU: the first pivots of NETGEN-like 1M nodes / 8M arcs, Best Eligible (9M search arcs per scan,
+    bucketed layout, resident grid looping over tiles).  Same-rule CPU port on the same first pivots beside it."""
+    g5 = M.netgen_like(SEED, 1_000_000, 8_000_000, 1000, 1000)
+    ns = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True)
+    ns.set_device(local_rank, 64, 0, 0).set_pivot_limit(gpu_pivots).prepare()
+    ns.solve()
+    m = ns.get_metrics(); it = max(m["iterations"], 1)
+    out = {"workload": "NETGEN-like 1M nodes / 8M arcs (config 5 on one GPU), Best Eligible, int64, first pivots only", "pivots": m["iterations"],
+           "us_per_pivot": m["loop_us"] / it, "pivot_search_us": m["pivot_search_us"] / it, "pivots_per_s": it / (m["loop_us"] / 1e6),
+           "search_arcs": m["search_arc_num"], "scan_GBps_incl_round_trip": m["engine"]["bytes_per_scan"] / (m["pivot_search_us"] / it) / 1e3}
+    del ns
+    if with_cpu:
+        b = cpu_baseline(g5, M.PivotRule.BestEligible, cpu_seconds)
+        out["cpu_port_same_rule"] = {"us_per_pivot": b["us_per_pivot"], "sample": b["sample"], "cores": 1}
+        out["gpu_over_cpu_per_pivot"] = b["us_per_pivot"] / out["us_per_pivot"]
+    return out
+
+
 def hbm_probe():
     """What this box's HBM delivers to a plain device-to-device copy (read + write), beside the nominal 8 TB/s used as `peak`."""
     import torch
@@ -409,6 +428,8 @@ def main():
     if not args.no_microbench and args.gpus == 1:
         line["scan_microbench"] = microbench()
         line["hbm_measured"] = hbm_probe()
+    if not args.no_microbench and args.gpus == 1:
+        line["large_instance_sample"] = large_instance_sample(M, local_rank, not args.no_cpu_baseline)
     if not args.no_validator and args.gpus == 1:
         line["solution_validator"] = validator_bench(M, g, solvers[0], local_rank, not args.no_cpu_baseline)
     print(json.dumps(line))
