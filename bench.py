@@ -128,7 +128,7 @@ def microbench():
 
 def large_instance_sample(M, local_rank, with_cpu, gpu_pivots=3000, cpu_seconds=4.0):
     """BASELINE.json configs[4] on ONE GPU: the first pivots of NETGEN-like 1M nodes / 8M arcs, Best Eligible (9M search arcs per scan,
-    bucketed layout, resident grid looping over tiles).  Same-rule CPU port on the same first pivots beside it."""
+    bucketed layout, one dispatch per search).  Same-rule CPU port on the same first pivots beside it."""
     g5 = M.netgen_like(SEED, 1_000_000, 8_000_000, 1000, 1000)
     ns = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True)
     ns.set_device(local_rank, 64, 0, 0).set_pivot_limit(gpu_pivots).prepare()
@@ -136,6 +136,7 @@ def large_instance_sample(M, local_rank, with_cpu, gpu_pivots=3000, cpu_seconds=
     m = ns.get_metrics(); it = max(m["iterations"], 1)
     out = {"workload": "NETGEN-like 1M nodes / 8M arcs (config 5 on one GPU), Best Eligible, int64, first pivots only", "pivots": m["iterations"],
            "us_per_pivot": m["loop_us"] / it, "pivot_search_us": m["pivot_search_us"] / it, "pivots_per_s": it / (m["loop_us"] / 1e6),
+           "engine_mode": "resident grid" if m["engine"]["resident"] else "one dispatch per search",
            "search_arcs": m["search_arc_num"], "scan_GBps_incl_round_trip": m["engine"]["bytes_per_scan"] / (m["pivot_search_us"] / it) / 1e3}
     del ns
     if with_cpu:

@@ -1003,6 +1003,9 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
     {
         const char *env = getenv("MCF_HIP_RESIDENT");
         bool want = (desc->flags & MCF_ENGINE_DISPATCH) == 0;      // resident unless dispatch mode is asked for
+        // arcs that fit neither registers nor (with their potentials) LDS are streamed from memory for every search anyway: one dispatch
+        // per search with 2048 workgroups is then faster than 256 resident ones (config 5: 71 vs 85 us per pivot)
+        if (!e->resident_reg && !e->lds_pi) want = false;
         if (env && env[0] == '1') want = true;
         if (env && env[0] == '0') want = false;
         const bool whole = e->begin == 0 && e->end == desc->search_arc_num;

@@ -454,6 +454,8 @@ def test_bucketed_layout_keeps_every_tie_break(mode, bucket, monkeypatch):
     """Arcs stored sorted by target-node range (MCF_HIP_BUCKET_NODES forces it on small inputs): same arc, same reduced cost, same state
     and potentials as the oracle, with tiny cost ranges so that ties between arcs of different ranges decide most searches."""
     monkeypatch.setenv("MCF_HIP_BUCKET_NODES", str(bucket))
+    if mode == 0:
+        monkeypatch.setenv("MCF_HIP_RESIDENT", "1")      # above 1M arcs the engine would pick one dispatch per search by itself
     rng = np.random.default_rng(77 + bucket)
     for m_s, n, span, width in [(50001, 17000, 2, 64), (400003, 100001, 3, 64), (300000, 20000, 10 ** 4, 32), (1_300_000, 30000, 2, 64)]:
         a = _random_soa(rng, m_s, n, span, span * 3)
