@@ -10,7 +10,8 @@
 // Default mode: ONE resident grid per solve; requests (sequence number, next_arc, the previous pivot's patches as final values) are
 // written by the host through the PCIe BAR into a mailbox in fine-grained VRAM, every workgroup applies all patches itself before it
 // reads anything, scans the arcs it keeps in registers and answers.  Dispatch mode (sharded engines, timing flags, no host-writable
-// VRAM): one scan dispatch per search with the patches in its kernel arguments.  See DESIGN.md section 3.
+// VRAM, instances too large for registers / LDS): one scan dispatch per search with the patches in its kernel arguments; large sparse
+// Best-Eligible instances are stored in bucketed order (build at upload, pos_of / d_orig).  See DESIGN.md sections 2 and 3.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <hsa/hsa.h>

@@ -1,8 +1,10 @@
 // kernels.hip.h -- device code of the pivot engine (included by engine.hip only).
 //
 //   scan_kernel / scan_kernel_lds   one dispatch per search: stream the SoA arc arrays, two potential gathers per arc, exact argmin
-//   resident_kernel                 one grid per solve: requests arrive through a mailbox in BAR-mapped VRAM, arcs live in registers
+//   resident_kernel                 one grid per solve: requests arrive through a mailbox in BAR-mapped VRAM; arcs (REG) and the potentials of
+//                                   their end points (PIREG) live in registers, or all potentials in LDS (LPI); CAND adds a candidate list
 //   update_kernel                   long patch lists in dispatch mode
+// PERM variants read arcs stored in bucketed order (sorted by target-node range) and break ties through the original arc ids.
 // No MFMA: there is no contraction on this path; it is bound by memory bandwidth, gather throughput and host <-> device latency.
 #pragma once
 
