@@ -7,7 +7,6 @@ import numpy as np
 
 sys.path.insert(0, ".")
 import mincostflow_amd as M
-from oracle import ns_oracle as O
 
 out = {}
 rng = np.random.default_rng(1)
