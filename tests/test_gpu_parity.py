@@ -44,7 +44,8 @@ def test_scan_matches_oracle_on_random_arrays(width, rule, optimized, mode):
     for m_s, n, span in [(1, 2, 3), (3, 2, 2), (4, 5, 2), (5, 3, 50), (1023, 40, 3), (1024, 300, 2), (1025, 7, 10 ** 6),
                          (4097, 5000, 4), (100003, 20000, 10 ** 4), (2 ** 20 + 5, 3000, 10 ** 5),
                          # potentials too many for LDS: register-resident potentials (<= 512 threads per workgroup) and, at 600k arcs, without
-                         (50001, 17000, 3), (400003, 100001, 10 ** 4), (600000, 50000, 5)]:
+                         (50001, 17000, 3), (400003, 100001, 10 ** 4), (600000, 50000, 5),
+                         (400003, 300000, 7)]:     # more nodes than bits in the patch bitmap of the resident grid: aliased bits
         pi_span = 10 ** 9 if width == 64 and span > 100 else span * 3
         a = _random_soa(rng, m_s, n, span, pi_span)
         block = int(rng.integers(1, max(2, min(m_s, 700))))
@@ -518,3 +519,18 @@ def test_bucketed_layout_on_arc_shards(monkeypatch):
         b, en = M.shard_range(m_s, shards.index(e), world)
         full[b:en] = st[b:en]
     assert np.array_equal(full, a["state"][:m_s])
+
+
+@pytest.mark.gpu
+def test_register_resident_potentials_pivot_for_pivot():
+    """A solve bigger than the bundled fixtures (20k nodes / 60k arcs: the potentials do not fit LDS), so the resident grid keeps the end
+    points' potentials in registers and sees every kind of patch list (one node ... more than 4096) in real proportions."""
+    g = M.netgen_like(7, 20_000, 60_000, 100, 100)
+    p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
+    for rule in (O.RULE_BEST, O.RULE_BLOCK):
+        o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, rule)
+        assert st == st_o == O.OPTIMAL
+        assert np.array_equal(ns.trace(), tr_o), int(np.argmax(ns.trace()[: len(tr_o)] != tr_o[: len(ns.trace())]))
+        assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
+        m = ns.get_metrics()
+        assert m["engine"]["resident"] == 1 and m["engine"]["scan_threads"] <= 512
