@@ -328,7 +328,10 @@ def main():
         avg_launch_ns = kernel_ns / max(launches, 1)
         achieved = bytes_per_launch / avg_launch_ns if avg_launch_ns > 0 else 0.0       # bytes/ns == GB/s
         in_kernel_ns = sum(x["resident_scan_ns"] for x in e) / max(requests, 1)
-        kernel_name = "resident_kernel<int64, BestEligible, REG, PIREG>" if mets[0]["engine"]["scan_threads"] <= 512 else "resident_kernel<int64, BestEligible, REG>"
+        rule_name = {0: "FirstEligible", 1: "BestEligible", 2: "BlockSearch"}[rule]
+        lds = g.node_count + 1 <= 16384
+        variant = "REG, LPI (potentials in LDS)" if lds else ("REG, PIREG (potentials in registers)" if e[0]["scan_threads"] <= 512 else "REG")
+        kernel_name = f"resident_kernel<int{width}, {rule_name}, {variant}>"
         extra = {"launches": launches, "requests_per_launch": requests / max(launches, 1), "avg_launch_ms": avg_launch_ns / 1e6,
                  "in_kernel": {"avg_request_us": in_kernel_ns / 1e3, "achieved": bytes_per_scan / in_kernel_ns if in_kernel_ns > 0 else 0.0,
                                "frac": bytes_per_scan / in_kernel_ns / HBM_PEAK_GBS if in_kernel_ns > 0 else 0.0,
@@ -338,7 +341,7 @@ def main():
         scan_ns = sum(x["timed_scan_ns"] for x in e) / max(timed, 1)
         bytes_per_launch = bytes_per_scan
         achieved = bytes_per_scan / scan_ns if scan_ns > 0 else 0.0
-        kernel_name = "scan_kernel<int64, BestEligible>"
+        kernel_name = f"scan_kernel<int{width}, " + {0: "FirstEligible", 1: "BestEligible", 2: "BlockSearch"}[rule] + ">"
         extra = {"avg_kernel_us": scan_ns / 1e3, "timed_launches": timed}
     # the same scan as a stand-alone dispatch on the same arrays (HIP events, 200 repetitions, warm)
     it0 = solvers[0].internal()

@@ -266,9 +266,20 @@ __device__ __forceinline__ void publish_best(Key best, Slot *slot, uint32_t tag,
     if ((tid & 63) == 0) wave_best[tid >> 6] = best;
     __syncthreads();
     if (tid < 64) {
-        Key k = wave_best[0];
+        // second stage: lane w takes wave w's result (at most 16 waves: one row of lanes), the same four row steps fold them
         const int waves = (int)(blockDim.x >> 6);          // NT is the largest block the kernel is launched with
-        for (int w = 1; w < waves; ++w) take_if_better<RULE>(k, wave_best[w].c, wave_best[w].r, wave_best[w].p);
+        const int w = tid < waves ? tid : 0;
+        Key k;
+        k.c = tid < waves ? wave_best[w].c : 0;
+        k.r = tid < waves ? wave_best[w].r : kNone;
+        k.p = tid < waves ? wave_best[w].p : kNone;
+        wave_min_step<RULE, kDppXor1>(k);
+        wave_min_step<RULE, kDppXor2>(k);
+        wave_min_step<RULE, kDppHalfMirror>(k);
+        wave_min_step<RULE, kDppMirror>(k);
+        k.c = lane_i64(k.c, 0);
+        k.p = lane_u32(k.p, 0);
+        k.r = lane_u32(k.r, 0);
         typedef uint32_t v4u __attribute__((ext_vector_type(4)));
         v4u out;
         out.x = (uint32_t)(uint64_t)k.c;
