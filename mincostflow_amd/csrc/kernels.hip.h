@@ -603,12 +603,12 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
         const int st_arc0 = (int)lm[6], st_arc1 = (int)lm[8];
         const uint32_t st_val0 = lm[7], st_val1 = lm[9];
         const uint32_t p0_node = lm[10], p0_lo = lm[11], p0_hi = lm[12];
-        __syncthreads();                                   // everybody has read line 0 before anybody overwrites lm
+        if (lines > 1) __syncthreads();                    // everybody has read lines 0 and 1 before the patch lines land in lm (uniform condition)
         if (timed_out) {
             if (tid == 0 && blockIdx.x == 0) resident_exit(p.exit_word, 2u, served, scan_ticks);
             return;
         }
-        const uint64_t t_seen = __builtin_amdgcn_s_memrealtime();
+        const uint64_t t_seen = blockIdx.x == 0 ? __builtin_amdgcn_s_memrealtime() : 0;     // only workgroup 0's clock is reported
         if (cmd != 0) {                                    // quit
             if (tid == 0 && blockIdx.x == 0) resident_exit(p.exit_word, 1u, served, scan_ticks);
             return;
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
         last = seq;
         served += 1;
         idle_since = __builtin_amdgcn_s_memrealtime();
-        scan_ticks += idle_since - t_seen;
+        if (blockIdx.x == 0) scan_ticks += idle_since - t_seen;
         if (fast) __builtin_amdgcn_s_waitcnt(0);           // the patches' stores have retired before anybody gathers again
         __syncthreads();                                   // lm and the reduction scratch are reused by the next request
     }
