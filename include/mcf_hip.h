@@ -132,6 +132,11 @@ MCF_API int mcf_engine_update_potential(mcf_engine *e, int32_t count, const int3
 /* Same as update_potential for callers that already hold the new values (the C++ host driver does: it keeps _pi itself):
  * pi[nodes[i]] = values[i]. */
 MCF_API int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values);
+/* Same, for a list that arrives in pieces (the subtree walk hands over what it has every few thousand nodes): may be called several
+ * times between two searches; the pieces of one pivot must not repeat a node (UpdatePotentials visits every node once, NS.cs:1196-1208).
+ * In resident mode the complete lines start travelling to the device at once and the grid applies them while the host is still
+ * walking; the next search finishes the list. */
+MCF_API int mcf_engine_append_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values);
 
 /* Rewrites (source, target, cost) of arcs, e.g. artificial arcs re-pointed by a warm start. Synchronous. */
 MCF_API int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, const int32_t *source,

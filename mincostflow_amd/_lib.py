@@ -103,6 +103,7 @@ SIGNATURES = {
     "mcf_engine_patch_state": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i8p]),
     "mcf_engine_update_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, C.c_int64]),
     "mcf_engine_set_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i64p]),
+    "mcf_engine_append_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i64p]),
     "mcf_engine_patch_arcs": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, _i64p]),
     "mcf_engine_find_entering": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
     "mcf_engine_find_entering_local": (C.c_int, [C.c_void_p, _P(Candidate)]),

@@ -127,6 +127,8 @@ struct mcf_engine {
     mcf_candidate *d_cand_local = nullptr, *d_cand_all = nullptr, *h_cand_all = nullptr;
     // resident mode (flag MCF_ENGINE_RESIDENT): mailbox in BAR-mapped fine-grained VRAM, exit record in pinned host memory
     bool resident_ok = false, resident_running = false, resident_reg = false;
+    int stream_lines = 0;          // entry lines of the coming request that an "apply" post has already put in place
+    uint32_t stream_sub = 0;       // counter of those posts
     uint32_t *mailbox = nullptr;
     int mailbox_lines = 0, mailbox_max_st = 0, poll_replicas = 8, poll_sleep = 1;
     uint32_t prev_seq = 0;
@@ -450,6 +452,7 @@ void resident_post(mcf_engine *e, uint32_t seq, uint32_t cmd, bool with_patches)
     alignas(16) uint32_t line1[16];
     memset(line1, 0, sizeof(line1));
     for (int l = 0, i = 0; i < entries; ++l) {
+        if (l > 0 && l + 1 <= e->stream_lines) { i += kMailboxPatchesPerLine; continue; }   // already in place (resident_stream); line 1 always goes out again
         memset(line, 0, sizeof(line));
         for (int k = 0; k < kMailboxPatchesPerLine && i < entries; ++k, ++i) {
             if (i < extra_pi) {
@@ -467,6 +470,7 @@ void resident_post(mcf_engine *e, uint32_t seq, uint32_t cmd, bool with_patches)
         if (l == 0) memcpy(line1, line, sizeof(line));                                  // line 1 goes out with every copy of the poll unit
         else mailbox_write_line(e->mailbox + kMailboxTail + 16 * (size_t)(l - 1), line);  // lines 2.. : the tail
     }
+    if (with_patches) e->stream_lines = 0;
     memset(line, 0, sizeof(line));
     line[0] = seq;
     line[1] = cmd;
@@ -497,6 +501,53 @@ void resident_post(mcf_engine *e, uint32_t seq, uint32_t cmd, bool with_patches)
     _mm_sfence();
 }
 
+// Long potential lists start travelling while the host is still producing them (mcf_engine_append_potential): the complete entry lines
+// gathered so far go into the mailbox and an "apply" post (cmd 2) tells the grid how far the list of the COMING scan request reaches.
+// No answer is expected; the posts are cumulative and the scan request finishes the list (kernels.hip.h, mailbox layout).
+constexpr int kStreamMinLines = 1024;          // 5120 entries per post: about what the grid applies while the host walks the next 5120 nodes
+
+void resident_stream(mcf_engine *e)
+{
+    if (!e->resident_running || e->cand_on || e->pend_arc.size() > 2) return;
+    const int n_pi = (int)e->pend_node.size();
+    const int complete = (n_pi > 1 ? n_pi - 1 : 0) / kMailboxPatchesPerLine;
+    if (complete - e->stream_lines < kStreamMinLines) return;
+    uint32_t next_seq = e->seq + 1;
+    if (next_seq == 0) next_seq = 1;
+    alignas(16) uint32_t line[16], line1[16];
+    memset(line1, 0, sizeof(line1));
+    for (int l = e->stream_lines == 0 ? 0 : e->stream_lines; l < complete; ++l) {          // l = entry line l + 1
+        memset(line, 0, sizeof(line));
+        for (int k = 0; k < kMailboxPatchesPerLine; ++k) {
+            const int i = l * kMailboxPatchesPerLine + k;
+            const uint64_t v = (uint64_t)e->pend_val[i + 1];
+            line[3 * k] = (uint32_t)e->pend_node[i + 1];
+            line[3 * k + 1] = (uint32_t)v;
+            line[3 * k + 2] = (uint32_t)(v >> 32);
+        }
+        line[15] = next_seq;
+        if (l == 0) memcpy(line1, line, sizeof(line));
+        else mailbox_write_line(e->mailbox + kMailboxTail + 16 * (size_t)(l - 1), line);
+    }
+    const bool first_post = e->stream_lines == 0;
+    e->stream_sub += 1;
+    if (e->stream_sub == 0) e->stream_sub = 1;
+    memset(line, 0, sizeof(line));
+    line[0] = next_seq;
+    line[1] = 2u;
+    line[13] = (uint32_t)complete;
+    line[14] = e->stream_sub;
+    line[15] = next_seq;
+    _mm_sfence();                                  // the entry lines leave the write-combining buffers before any header does
+    for (int r = 0; r < e->poll_replicas; ++r) {
+        uint32_t *unit = e->mailbox + (size_t)r * kReplicaStride;
+        if (first_post) mailbox_write_line(unit + 16, line1);
+        mailbox_write_line(unit, line);
+    }
+    _mm_sfence();
+    e->stream_lines = complete;
+}
+
 int resident_stop(mcf_engine *e)
 {
     if (!e->resident_running) return MCF_OK;
@@ -506,6 +557,7 @@ int resident_stop(mcf_engine *e)
     resident_post(e, e->seq, 1u, false);
     HIP_TRY(hipStreamSynchronize(e->stream));       // bounded: the grid leaves on quit, or by itself after kResidentIdleTicks
     e->resident_running = false;
+    e->stream_lines = 0;
     const volatile uint32_t *x = e->h_exit;
     e->st.resident_requests += x[1];
     e->st.resident_scan_ns += 10.0 * (double)(((uint64_t)x[3] << 32) | x[2]);
@@ -1256,6 +1308,27 @@ int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes,
     e->pend_val.assign(values, values + count);
     e->mirror_valid = false;
     e->st.potential_nodes += count;
+    resident_stream(e);       // a long list starts travelling now; the search only has to finish it
+    return MCF_OK;
+}
+
+int mcf_engine_append_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values)
+{
+    if (!e || count < 0 || (count && (!nodes || !values))) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_append_potential: bad arguments");
+    if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
+    if (count == 0) return MCF_OK;
+    if (e->cand_on || e->pend_node.empty()) return mcf_engine_set_potential(e, count, nodes, values);     // nothing queued yet / candidate mode takes any number of calls
+    if ((int64_t)e->pend_node.size() + count > e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "more nodes appended than the graph has: the lists of one pivot must not repeat nodes");
+    const bool narrow = e->d.int_width == 32;
+    for (int i = 0; i < count; ++i) {
+        if ((unsigned)nodes[i] >= (unsigned)e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "node %d out of range", nodes[i]);
+        if (narrow && !fits32(values[i])) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d leaves int32; create the engine with int_width 64", nodes[i]);
+    }
+    e->pend_node.insert(e->pend_node.end(), nodes, nodes + count);
+    e->pend_val.insert(e->pend_val.end(), values, values + count);
+    e->mirror_valid = false;
+    e->st.potential_nodes += count;
+    resident_stream(e);
     return MCF_OK;
 }
 

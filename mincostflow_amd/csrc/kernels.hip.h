@@ -523,8 +523,11 @@ __device__ __forceinline__ void publish_candidates(int64_t c1, uint32_t p1, int6
 }
 
 // Mailbox: lines of 64 bytes; dword 15 of EVERY line repeats seq, so a torn read of any line is detected and retried.
-//   line 0      [0] seq [1] cmd (0 scan, 1 quit) [2] next_arc [3] rstar [4] n_pi [5] n_st [6..9] state patches 0,1 {arc, value}
-//               [10..12] potential patch 0 {node, lo, hi}
+//   line 0      [0] seq [1] cmd (0 scan, 1 quit, 2 apply) [2] next_arc [3] rstar [4] n_pi [5] n_st [6..9] state patches 0,1 {arc, value}
+//               [10..12] potential patch 0 {node, lo, hi} [13] apply: entry lines valid so far [14] apply: post counter
+// cmd 2 ("apply") streams a long potential list while the host is still walking the subtree: the entry lines 1..[13] of the NEXT scan
+// request are in place, every workgroup applies those it has not applied yet and goes back to polling (no answer).  The posts are
+// cumulative, so one that is overwritten before a workgroup saw it loses nothing; the scan request finishes the list.
 //   line 1..    five entries {a, b, c} each: potential patches 1..n_pi-1 {node, lo, hi}, then state patches 2..n_st-1 {arc, value, 0}
 // The poll reads line 0 only (one 64-byte read per workgroup per poll); the other lines are fetched when there are more entries.
 //
@@ -566,7 +569,8 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
         __syncthreads();
     }
     const T *const pi_view = LPI ? lpi : p.pi;
-    uint32_t last = p.start_seq, served = 0;
+    uint32_t last = p.start_seq, served = 0, last_sub = 0;
+    int applied = 0;                                          // entry lines of the coming scan request already applied (cmd 2)
     uint64_t scan_ticks = 0;
     uint64_t idle_since = __builtin_amdgcn_s_memrealtime();
     const uint32_t *const my_unit = p.mailbox + (size_t)(blockIdx.x % p.poll_replicas) * kReplicaStride;   // this workgroup's copy of lines 0, 1
@@ -580,8 +584,8 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
             for (;;) {
                 if (tid < 8) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x) : "v"(my_unit + tid * 4) : "memory");
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)::"memory");
-                const uint32_t seq0 = lane_u32(x[0], 0), tag0 = lane_u32(x[3], 3);
-                if (seq0 != last && tag0 == seq0) { flag = 1u; break; }
+                const uint32_t seq0 = lane_u32(x[0], 0), tag0 = lane_u32(x[3], 3), cmd0 = lane_u32(x[1], 0), sub0 = lane_u32(x[2], 3);
+                if (seq0 != last && tag0 == seq0 && (cmd0 != 2u || sub0 != last_sub)) { flag = 1u; break; }
                 if (__builtin_amdgcn_s_memrealtime() - idle_since > p.idle_ticks) { flag = 2u; break; }
                 for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
             }
@@ -595,10 +599,14 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
         n_st = n_st < 0 ? 0 : (n_st > p.max_st ? p.max_st : n_st);
         const int extra_pi = n_pi > 1 ? n_pi - 1 : 0, extra_st = n_st > 2 ? n_st - 2 : 0;
         const int entries = extra_pi + extra_st;
-        const int lines = 1 + (entries + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
+        const uint32_t cmd = lm[1];
+        const bool apply_only = cmd == 2u;
+        const uint32_t sub = lm[14];
+        int upto = (int)lm[13];                              // apply: the last entry line in place
+        upto = upto < 0 ? 0 : (upto > (p.max_pi + p.max_st) / kMailboxPatchesPerLine ? (p.max_pi + p.max_st) / kMailboxPatchesPerLine : upto);
+        const int lines = apply_only ? 1 + upto : 1 + (entries + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
         const bool timed_out = s_timeout == 2u;
         const bool line1_staged = lm[31] == seq;           // line 1 came along with the poll and is complete
-        const uint32_t cmd = lm[1];
         const int next_arc = (int)lm[2], rstar = (int)lm[3];
         const int st_arc0 = (int)lm[6], st_arc1 = (int)lm[8];
         const uint32_t st_val0 = lm[7], st_val1 = lm[9];
@@ -609,16 +617,19 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
             return;
         }
         const uint64_t t_seen = blockIdx.x == 0 ? __builtin_amdgcn_s_memrealtime() : 0;     // only workgroup 0's clock is reported
-        if (cmd != 0) {                                    // quit
+        if (cmd == 1u) {                                   // quit
             if (tid == 0 && blockIdx.x == 0) resident_exit(p.exit_word, 1u, served, scan_ticks);
             return;
         }
         // ---- patches: final values, applied by EVERY workgroup before it reads (same argument as scan_kernel).
         // The entries beyond the header come in chunks of 255 lines (1275 entries), each line verified by its tag before use.
         // PIREG: 0 = nothing beyond the header, 1 = compare directly, 2 = bitmap + gather the hits, 3 = gather everything again
-        const int pr_mode = !PIREG ? 0 : (entries == 0 ? 0 : (entries <= kPiRegCompare ? 1 : (entries <= kPiRegBitmapMax ? 2 : 3)));
+        // a streamed list (apply posts seen, or this is one) only stores; the scan request then gathers everything again (mode 3)
+        const int pr_mode = !PIREG ? 0 : ((apply_only || applied > 0) ? 3 : (entries == 0 ? 0 : (entries <= kPiRegCompare ? 1 : (entries <= kPiRegBitmapMax ? 2 : 3))));
+        const int entries_here = apply_only ? upto * kMailboxPatchesPerLine : entries;      // entries that lines 1 .. lines-1 hold
+        const int pi_here = apply_only ? entries_here : extra_pi;                          // ... of which potential patches come first
         bool torn = false;
-        for (int first = 1; first < lines; first += kChunk) {
+        for (int first = applied + 1; first < lines; first += kChunk) {
             const int chunk = lines - first < kChunk ? lines - first : kChunk;
             const bool staged = first == 1 && chunk == 1 && line1_staged;
             for (int base = 0; base < chunk * 4 && !staged; base += nt * 4) {      // up to four 16-byte reads per thread in flight, one wait
@@ -646,11 +657,11 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
             for (int l = tid; l < chunk; l += nt) bad |= (lm[(1 + l) * 16 + 15] != seq);
             if (__syncthreads_or(bad)) { torn = true; break; }
             const int i_lo = (first - 1) * kMailboxPatchesPerLine;                    // entry index of the chunk's first entry
-            const int i_hi = entries < i_lo + chunk * kMailboxPatchesPerLine ? entries : i_lo + chunk * kMailboxPatchesPerLine;
+            const int i_hi = entries_here < i_lo + chunk * kMailboxPatchesPerLine ? entries_here : i_lo + chunk * kMailboxPatchesPerLine;
             for (int i = i_lo + tid; i < i_hi; i += nt) {
                 const int rel = i - i_lo;
                 const uint32_t *q = lm + (1 + rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
-                if (i < extra_pi) {
+                if (i < pi_here) {
                     const int64_t v = (int64_t)(((uint64_t)q[2] << 32) | q[1]);
                     p.pi[q[0]] = (T)v;
                     if (LPI) lpi[q[0]] = (T)v;
@@ -661,7 +672,7 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
                 }
             }
             if (pr_mode == 1) {                             // every thread matches the chunk's potential patches against its eight end points
-                const int hi_pi = i_hi < extra_pi ? i_hi : extra_pi;
+                const int hi_pi = i_hi < pi_here ? i_hi : pi_here;
                 for (int i = i_lo; i < hi_pi; ++i) {
                     const int rel = i - i_lo;
                     const uint32_t *q = lm + (1 + rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
@@ -671,7 +682,7 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
                     for (int j = 0; j < 4; ++j) { ps[j] = mine.s.v[j] == node ? v : ps[j]; pt[j] = mine.t.v[j] == node ? v : pt[j]; }
                 }
             }
-            if (REG && extra_st > 0) {                      // every thread checks the chunk's state patches against its four arcs
+            if (REG && extra_st > 0 && !apply_only) {       // every thread checks the chunk's state patches against its four arcs
                 const int s_lo = i_lo > extra_pi ? i_lo : extra_pi;
                 for (int i = s_lo; i < i_hi; ++i) {
                     const int rel = i - i_lo;
@@ -683,9 +694,16 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
             __syncthreads();                               // the chunk has been consumed before the next one lands in lm
         }
         if (torn) continue;                                // a line was still in flight: poll again (re-applying final values is harmless)
+        if (apply_only) {                                  // part of a list: remember how far it got, no answer
+            applied = upto > applied ? upto : applied;
+            last_sub = sub;
+            idle_since = __builtin_amdgcn_s_memrealtime();
+            __syncthreads();
+            continue;
+        }
         // header patches.  With nothing but them (n_pi <= 1, n_st <= 2) and register-resident arcs nobody has to wait for the stores:
         // the potential is substituted from the request while its store retires behind the scan.
-        const bool fast = REG && (entries == 0 || pr_mode == 1);
+        const bool fast = REG && (entries == 0 || pr_mode == 1) && applied == 0;
         const T v0 = (T)(int64_t)(((uint64_t)p0_hi << 32) | p0_lo);
         if (n_pi | n_st) {
             if (tid == 0 && n_pi > 0) { p.pi[p0_node] = v0; if (LPI) lpi[p0_node] = v0; }
@@ -745,6 +763,7 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
             publish_best<RULE, true, kResidentThreads>(best, p.slots + (size_t)blockIdx.x * kSlotStride, seq, true);
         }
         last = seq;
+        applied = 0;
         served += 1;
         idle_since = __builtin_amdgcn_s_memrealtime();
         if (blockIdx.x == 0) scan_ticks += idle_since - t_seen;

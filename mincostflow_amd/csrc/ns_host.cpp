@@ -50,6 +50,9 @@ struct mcf_ns {
     std::vector<int32_t> moved;       // capacity n+1, the first moved_n entries are valid
     std::vector<int64_t> moved_val;   // their new potentials
     int moved_n = 0;
+    int moved_sent = 0;               // how many of them the engine already has (handed over during the walk)
+    int engine_rc = 0;                // first error of an engine call made from inside a pivot
+    bool hand_over = false;           // a device engine is attached: state writes and potential pieces go to it as they arise
     int64_t sigma = 0;
     // engine + sharding
     mcf_engine *engine = nullptr;
@@ -278,6 +281,7 @@ void rehang_subtree(mcf_ns *s)
 //    prefetches the lines it will need kWalkAhead steps from now; a stale hint costs a useless prefetch, nothing else.
 // The order of the resulting list is irrelevant to the engine (final values).
 constexpr int kWalkAhead = 8, kWalkHintMin = 48;
+constexpr int kWalkPiece = 8192;   // a big walk hands its nodes to the engine in pieces of this size (mcf_engine_append_potential)
 
 void shift_potentials(mcf_ns *s)
 {
@@ -310,6 +314,11 @@ void shift_potentials(mcf_ns *s)
         vals[i] = (pi[a] += sigma);
         if (i >= kWalkAhead) follow[nodes[i - kWalkAhead]] = a;
         a = nxt[a];
+        if (s->hand_over && i + 1 - s->moved_sent >= kWalkPiece && count - (i + 1) >= kWalkPiece / 2) {
+            // the grid applies this piece while the walk goes on (resident mode); the search after the pivot finishes the list
+            if (!s->engine_rc) s->engine_rc = mcf_engine_append_potential(s->engine, i + 1 - s->moved_sent, nodes + s->moved_sent, vals + s->moved_sent);
+            s->moved_sent = i + 1;
+        }
     }
 }
 
@@ -318,11 +327,14 @@ bool pivot(mcf_ns *s, int arc, double *t_tree, double *t_pot)
 {
     s->in_arc = arc;
     s->moved_n = 0;
+    s->moved_sent = 0;
     s->sigma = 0;
     find_join(s);
     const bool change = find_leaving(s);
     if (!change && s->delta == 0) return true;
     push_flow(s, change);
+    // the engine hears about the state writes before any piece of the potential list (the pieces may start travelling at once)
+    if (s->hand_over && !s->engine_rc) s->engine_rc = mcf_engine_patch_state(s->engine, s->n_state, s->st_arc, s->st_val);
     if (s->delta == 0) s->metrics.degenerate_pivots++;
     if (change) {
         const double t0 = mcf::now_ns();
@@ -596,6 +608,8 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     int64_t it = 0;
     bool limited = false;
     double t_search = 0, t_tree = 0, t_pot = 0;
+    s->hand_over = true;
+    s->engine_rc = 0;
     for (;;) {
         const double t0 = mcf::now_ns();
         int32_t found = 0, arc = -1;
@@ -610,12 +624,14 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         if (s->pivot_limit && it > s->pivot_limit) { --it; limited = true; break; }
         if (pivot(s, arc, &t_tree, &t_pot)) { s->status = MCF_UNBOUNDED; break; }
         const double t1 = mcf::now_ns();
-        rc = mcf_engine_patch_state(s->engine, s->n_state, s->st_arc, s->st_val);
-        if (!rc && s->moved_n) rc = mcf_engine_set_potential(s->engine, (int32_t)s->moved_n, s->moved.data(), s->moved_val.data());
+        rc = s->engine_rc;
+        if (!rc && s->moved_n > s->moved_sent)
+            rc = mcf_engine_append_potential(s->engine, (int32_t)(s->moved_n - s->moved_sent), s->moved.data() + s->moved_sent, s->moved_val.data() + s->moved_sent);
         t_pot += mcf::now_ns() - t1;
         if (rc) return rc;
         s->metrics.potential_nodes += (int64_t)s->moved_n;
     }
+    s->hand_over = false;
     mcf_engine_park(s->engine);      // a resident scan grid must not outlive Solve()
     s->trace_len = std::min(it, s->trace_cap);
     s->metrics.iterations = it;

@@ -323,6 +323,10 @@ class PivotEngine:
         nodes, values = _i32(nodes), _i64(values)
         L.check(L.lib().mcf_engine_set_potential(self._h, len(nodes), nodes, values))
 
+    def append_potential(self, nodes, values):
+        nodes, values = _i32(nodes), _i64(values)
+        L.check(L.lib().mcf_engine_append_potential(self._h, nodes.shape[0], nodes, values))
+
     def patch_arcs(self, arcs, source, target, cost):
         arcs = _i32(arcs)
         L.check(L.lib().mcf_engine_patch_arcs(self._h, len(arcs), arcs, _i32(source), _i32(target), _i64(cost)))

@@ -534,3 +534,30 @@ def test_register_resident_potentials_pivot_for_pivot():
         assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
         m = ns.get_metrics()
         assert m["engine"]["resident"] == 1 and m["engine"]["scan_threads"] <= 512
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("m_s,n", [(400003, 100001), (60001, 16000), (1_300_000, 40000)])
+def test_potential_lists_that_arrive_in_pieces(mode, m_s, n):
+    """mcf_engine_append_potential: the list of one pivot handed over in several calls (disjoint nodes); in resident mode the complete lines
+    travel at once (apply posts) and the search finishes the list.  Every engine mode, potentials in registers / LDS / memory."""
+    rng = np.random.default_rng(31 + m_s)
+    a = _random_soa(rng, m_s, n, 3, 9)
+    eng = M.PivotEngine(n, len(a["src"]), m_s, rule=M.PivotRule.BestEligible, optimized=True, flags=mode)
+    eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+    for it in range(8):
+        f, e, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+        f2, e2, c2 = eng.find_entering()
+        assert f2 == f and (not f or (e2, c2) == (e, c)), (it, e2, e, c2, c)
+        arcs = rng.choice(m_s, size=2, replace=False).astype(np.int32); vals = rng.integers(-1, 2, 2).astype(np.int8)
+        a["state"][arcs] = vals
+        eng.patch_state(arcs, vals)
+        total = int(rng.choice([3, 5200, 11000, min(n - 1, 15900), min(n - 1, 60000)]))
+        nodes = rng.choice(n, size=total, replace=False).astype(np.int32)
+        a["pi"][nodes] += int(rng.integers(-4, 5))
+        cuts = sorted(set([0, total] + [int(x) for x in rng.integers(0, total + 1, int(rng.integers(0, 5)))]))
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            eng.append_potential(nodes[lo:hi], a["pi"][nodes[lo:hi]])
+    assert np.array_equal(eng.download_pi(), a["pi"])
+    assert np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
