@@ -504,7 +504,7 @@ void resident_post(mcf_engine *e, uint32_t seq, uint32_t cmd, bool with_patches)
 // Long potential lists start travelling while the host is still producing them (mcf_engine_append_potential): the complete entry lines
 // gathered so far go into the mailbox and an "apply" post (cmd 2) tells the grid how far the list of the COMING scan request reaches.
 // No answer is expected; the posts are cumulative and the scan request finishes the list (kernels.hip.h, mailbox layout).
-constexpr int kStreamMinLines = 1024;          // 5120 entries per post: about what the grid applies while the host walks the next 5120 nodes
+constexpr int kStreamMinLines = 768;           // 3840 entries per post at least: one piece of the host driver's walk (4096 nodes)
 
 void resident_stream(mcf_engine *e)
 {
