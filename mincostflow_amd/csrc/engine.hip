@@ -127,6 +127,9 @@ struct mcf_engine {
     mcf_candidate *d_cand_local = nullptr, *d_cand_all = nullptr, *h_cand_all = nullptr;
     // resident mode (flag MCF_ENGINE_RESIDENT): mailbox in BAR-mapped fine-grained VRAM, exit record in pinned host memory
     bool resident_ok = false, resident_running = false, resident_reg = false;
+    // host-side phase times are counted in time-stamp-counter ticks (a clock call costs 20+ ns, four of them per search) and scaled to ns
+    // in mcf_engine_get_stats against the wall clock since creation
+    double wait_ticks = 0, launch_ticks = 0, cal_ns = 0, cal_ticks = 0;
     int stream_lines = 0;          // entry lines of the coming request that an "apply" post has already put in place
     uint32_t stream_sub = 0;       // counter of those posts
     uint32_t *mailbox = nullptr;
@@ -570,7 +573,8 @@ int resident_stop(mcf_engine *e)
 int collect(mcf_engine *e, int grid, Key *out)
 {
     constexpr int stride = kSlotStride;
-    const double t0 = mcf::now_ns();
+    const double t0 = (double)__rdtsc();
+    double t0_wall = 0;
     const bool block_rule = e->d.rule == MCF_RULE_BLOCK_SEARCH, best_rule = e->d.rule == MCF_RULE_BEST_ELIGIBLE;
     Key best{0, kNone, kNone};
     const volatile Slot *slots = e->h_slots;
@@ -598,7 +602,8 @@ int collect(mcf_engine *e, int grid, Key *out)
             if ((++spins & 0xFFFFF) == 0) {
                 const hipError_t q = hipStreamQuery(e->stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return mcf::fail(MCF_ERR_HIP, "scan dispatch failed: %s", hipGetErrorString(q));
-                if (mcf::now_ns() - t0 > 20e9) return mcf::fail(MCF_ERR_TIMEOUT, "no answer from the device after 20 s (workgroup %d of %d)", g, grid);
+                if (t0_wall == 0) t0_wall = mcf::now_ns();
+                else if (mcf::now_ns() - t0_wall > 20e9) return mcf::fail(MCF_ERR_TIMEOUT, "no answer from the device after 20 s (workgroup %d of %d)", g, grid);
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
@@ -618,7 +623,7 @@ int collect(mcf_engine *e, int grid, Key *out)
         }
         if (take) best = k;
     }
-    e->st.host_wait_ns += mcf::now_ns() - t0;
+    e->wait_ticks += (double)__rdtsc() - t0;
     *out = best;
     return MCF_OK;
 }
@@ -737,7 +742,8 @@ bool cand_try_host(mcf_engine *e, Key *k)
 // wait for the candidate records of request `seq` and rebuild the list
 int cand_collect(mcf_engine *e, Key *out)
 {
-    const double t0 = mcf::now_ns();
+    const double t0 = (double)__rdtsc();
+    double t0_wall = 0;
     const volatile Slot *slots = e->h_slots;
     const uint32_t seq = e->seq;
     e->cand_list.clear();
@@ -759,7 +765,8 @@ int cand_collect(mcf_engine *e, Key *out)
             if ((++spins & 0xFFFFF) == 0) {
                 const hipError_t q = hipStreamQuery(e->stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return mcf::fail(MCF_ERR_HIP, "resident grid failed: %s", hipGetErrorString(q));
-                if (mcf::now_ns() - t0 > 20e9) return mcf::fail(MCF_ERR_TIMEOUT, "no answer from the device after 20 s (workgroup %d of %d)", g, e->res_grid);
+                if (t0_wall == 0) t0_wall = mcf::now_ns();
+                else if (mcf::now_ns() - t0_wall > 20e9) return mcf::fail(MCF_ERR_TIMEOUT, "no answer from the device after 20 s (workgroup %d of %d)", g, e->res_grid);
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
@@ -770,7 +777,7 @@ int cand_collect(mcf_engine *e, Key *out)
             if (e->cand_thr.p == kNone || cand_key_less(t, e->cand_thr)) e->cand_thr = t;
         }
     }
-    e->st.host_wait_ns += mcf::now_ns() - t0;
+    e->wait_ticks += (double)__rdtsc() - t0;
     if (e->cand_thr.p != kNone) {      // keep only what is provably complete: keys below the smallest unreported key
         size_t keep = 0;
         for (size_t i = 0; i < e->cand_list.size(); ++i)
@@ -806,7 +813,7 @@ void cand_reset_dirty(mcf_engine *e)
 int local_search(mcf_engine *e, Key *k)
 {
     if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
-    const double t0 = mcf::now_ns();
+    const double t0 = (double)__rdtsc();
     const bool had = !e->pend_node.empty() || !e->pend_arc.empty();
     if (e->cand_on) {
         // ---- candidate cache: answer from the host when that is provably the scan's answer
@@ -832,7 +839,7 @@ int local_search(mcf_engine *e, Key *k)
         if (had || !e->pend_node.empty()) e->st.inline_updates += 1;
         e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
         cand_reset_dirty(e);
-        e->st.host_launch_ns += mcf::now_ns() - t0;
+        e->launch_ticks += (double)__rdtsc() - t0;
         e->st.searches += 1;
         e->st.arcs_scanned += e->end - e->begin;
         return cand_collect(e, k);
@@ -856,7 +863,7 @@ int local_search(mcf_engine *e, Key *k)
             if (had) e->st.inline_updates += 1;
             e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
         }
-        e->st.host_launch_ns += mcf::now_ns() - t0;
+        e->launch_ticks += (double)__rdtsc() - t0;
         e->st.searches += 1;
         e->st.arcs_scanned += e->end - e->begin;
         return collect(e, e->res_grid, k);
@@ -874,7 +881,7 @@ int local_search(mcf_engine *e, Key *k)
         if (had) e->st.inline_updates += 1;
         e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
     }
-    e->st.host_launch_ns += mcf::now_ns() - t0;
+    e->launch_ticks += (double)__rdtsc() - t0;
     e->st.searches += 1;
     rc = collect(e, e->grid, k);
     if (rc) return rc;
@@ -974,6 +981,8 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         return mcf::fail(MCF_ERR_NO_DEVICE, "HIP device %d not available (%d visible); this library has no CPU search path", desc->device, mcf_device_count());
     HIP_TRY(hipSetDevice(desc->device));
     mcf_engine *e = new mcf_engine();
+    e->cal_ns = mcf::now_ns();
+    e->cal_ticks = (double)__rdtsc();
     e->d = *desc;
     e->begin = desc->shard_begin;
     e->end = desc->shard_end;
@@ -1468,6 +1477,9 @@ int mcf_engine_get_stats(mcf_engine *e, mcf_engine_stats *out)
     int rc = resident_stop(e);
     if (!rc) rc = drain_events(e, true);
     if (rc) return rc;
+    const double ns_per_tick = (mcf::now_ns() - e->cal_ns) / std::max(1.0, (double)__rdtsc() - e->cal_ticks);
+    e->st.host_wait_ns = e->wait_ticks * ns_per_tick;
+    e->st.host_launch_ns = e->launch_ticks * ns_per_tick;
     *out = e->st;
     return MCF_OK;
 }
@@ -1479,6 +1491,7 @@ int mcf_engine_reset_stats(mcf_engine *e)
     drain_events(e, true);
     const mcf_engine_stats keep = e->st;
     e->st = mcf_engine_stats{};
+    e->wait_ticks = e->launch_ticks = 0;
     e->st.scan_workgroups = keep.scan_workgroups;
     e->st.scan_threads = keep.scan_threads;
     e->st.bytes_per_scan = keep.bytes_per_scan;

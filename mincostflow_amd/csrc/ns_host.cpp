@@ -11,9 +11,13 @@
 #include <cstring>
 #include <vector>
 
+#include <x86intrin.h>
+
 #include "common.h"
 
 namespace {
+
+inline double ticks() { return (double)__rdtsc(); }     // invariant TSC; scaled to ns once per solve
 
 constexpr int8_t kUp = 1, kDown = -1;   // SpanningTree.cs:67-71 DIR_UP / DIR_DOWN
 constexpr int64_t kMax = INT64_MAX;     // NS.cs:126
@@ -338,11 +342,11 @@ bool pivot(mcf_ns *s, int arc, double *t_tree, double *t_pot)
     if (s->hand_over && !s->engine_rc) s->engine_rc = mcf_engine_patch_state(s->engine, s->n_state, s->st_arc, s->st_val);
     if (s->delta == 0) s->metrics.degenerate_pivots++;
     if (change) {
-        const double t0 = mcf::now_ns();
+        const double t0 = ticks();
         rehang_subtree(s);
-        const double t1 = mcf::now_ns();
+        const double t1 = ticks();
         shift_potentials(s);
-        const double t2 = mcf::now_ns();
+        const double t2 = ticks();
         if (t_tree) *t_tree += t1 - t0;
         if (t_pot) *t_pot += t2 - t1;
     }
@@ -604,6 +608,7 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     s->solved = true;
     if (s->status == MCF_INFEASIBLE) { if (status) *status = s->status; return MCF_OK; }
     const double t_start = mcf::now_ns();
+    const double tick_start = ticks();
 
     const int64_t max_iter = std::max<int64_t>(1000000, (int64_t)s->n * (int64_t)s->m);   // NS.cs:280
     int64_t it = 0;
@@ -612,11 +617,11 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     s->hand_over = true;
     s->engine_rc = 0;
     for (;;) {
-        const double t0 = mcf::now_ns();
+        const double t0 = ticks();
         int32_t found = 0, arc = -1;
         rc = s->sharded ? mcf_engine_find_entering_sharded(s->engine, &found, &arc, nullptr)
                         : mcf_engine_find_entering(s->engine, &found, &arc, nullptr);
-        t_search += mcf::now_ns() - t0;
+        t_search += ticks() - t0;
         if (rc) return rc;
         if (!found) break;
         if (s->trace && it < s->trace_cap) s->trace[it] = arc;
@@ -624,11 +629,11 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         if (it > max_iter) { s->status = MCF_INFEASIBLE; break; }                          // NS.cs:311-317
         if (s->pivot_limit && it > s->pivot_limit) { --it; limited = true; break; }
         if (pivot(s, arc, &t_tree, &t_pot)) { s->status = MCF_UNBOUNDED; break; }
-        const double t1 = mcf::now_ns();
+        const double t1 = ticks();
         rc = s->engine_rc;
         if (!rc && s->moved_n > s->moved_sent)
             rc = mcf_engine_append_potential(s->engine, (int32_t)(s->moved_n - s->moved_sent), s->moved.data() + s->moved_sent, s->moved_val.data() + s->moved_sent);
-        t_pot += mcf::now_ns() - t1;
+        t_pot += ticks() - t1;
         if (rc) return rc;
         s->metrics.potential_nodes += (int64_t)s->moved_n;
     }
@@ -637,9 +642,11 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     s->trace_len = std::min(it, s->trace_cap);
     s->metrics.iterations = it;
     if (s->status == MCF_NOT_SOLVED && !limited) finish(s);
-    s->metrics.pivot_search_us = t_search / 1e3;
-    s->metrics.tree_update_us = t_tree / 1e3;
-    s->metrics.potential_update_us = t_pot / 1e3;
+    // the phase buckets were counted in time-stamp-counter ticks (a clock call per phase costs 20+ ns, seven of them per pivot): scale them
+    const double ns_per_tick = (mcf::now_ns() - t_start) / std::max(1.0, ticks() - tick_start);
+    s->metrics.pivot_search_us = t_search * ns_per_tick / 1e3;
+    s->metrics.tree_update_us = t_tree * ns_per_tick / 1e3;
+    s->metrics.potential_update_us = t_pot * ns_per_tick / 1e3;
     mcf_engine_get_stats(s->engine, &s->metrics.engine);
     s->metrics.loop_us = (mcf::now_ns() - t_start) / 1e3;
     s->metrics.total_solve_us = s->metrics.loop_us + s->metrics.setup_us;
