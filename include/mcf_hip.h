@@ -146,6 +146,11 @@ MCF_API int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *a
  * *reduced_cost = state*(cost + pi[source] - pi[target]) of that arc.  Advances the rule's internal next_arc exactly
  * as the selected reference implementation does. */
 MCF_API int mcf_engine_find_entering(mcf_engine *e, int32_t *found, int32_t *arc, int64_t *reduced_cost);
+/* The same search in two halves: _begin posts it and returns, _end waits for the answer.  Between the two the host may do whatever
+ * the search does not depend on (the reference's ChangeFlow arithmetic and UpdateTreeStructure of the pivot just made: the device
+ * only needs the State[] writes and the potentials); patches queued in between belong to the NEXT search.  find_entering = both. */
+MCF_API int mcf_engine_search_begin(mcf_engine *e);
+MCF_API int mcf_engine_search_end(mcf_engine *e, int32_t *found, int32_t *arc, int64_t *reduced_cost);
 
 /* Sharded search: the local candidate of this engine's shard, as an exchangeable 16-byte record. */
 typedef struct mcf_candidate {

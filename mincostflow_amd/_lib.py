@@ -106,6 +106,8 @@ SIGNATURES = {
     "mcf_engine_append_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i64p]),
     "mcf_engine_patch_arcs": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, _i64p]),
     "mcf_engine_find_entering": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
+    "mcf_engine_search_begin": (C.c_int, [C.c_void_p]),
+    "mcf_engine_search_end": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
     "mcf_engine_find_entering_local": (C.c_int, [C.c_void_p, _P(Candidate)]),
     "mcf_engine_resolve": (C.c_int, [C.c_void_p, C.c_int32, _P(Candidate), _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
     "mcf_resolve_candidates": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), C.c_int32, _P(Candidate),

@@ -130,6 +130,10 @@ struct mcf_engine {
     // host-side phase times are counted in time-stamp-counter ticks (a clock call costs 20+ ns, four of them per search) and scaled to ns
     // in mcf_engine_get_stats against the wall clock since creation
     double wait_ticks = 0, launch_ticks = 0, cal_ns = 0, cal_ticks = 0;
+    // a search that has been posted / launched but not collected yet (mcf_engine_search_begin .. _end)
+    enum { kNoSearch = 0, kAnswered, kResidentSearch, kCandSearch, kDispatchSearch } in_flight = kNoSearch;
+    Key answered{0, kNone, kNone};
+    bool in_flight_timed = false;
     int stream_lines = 0;          // entry lines of the coming request that an "apply" post has already put in place
     uint32_t stream_sub = 0;       // counter of those posts
     uint32_t *mailbox = nullptr;
@@ -511,7 +515,7 @@ constexpr int kStreamMinLines = 768;           // 3840 entries per post at least
 
 void resident_stream(mcf_engine *e)
 {
-    if (!e->resident_running || e->cand_on || e->pend_arc.size() > 2) return;
+    if (!e->resident_running || e->cand_on || e->pend_arc.size() > 2 || e->in_flight != mcf_engine::kNoSearch) return;
     const int n_pi = (int)e->pend_node.size();
     const int complete = (n_pi > 1 ? n_pi - 1 : 0) / kMailboxPatchesPerLine;
     if (complete - e->stream_lines < kStreamMinLines) return;
@@ -551,9 +555,19 @@ void resident_stream(mcf_engine *e)
     e->stream_lines = complete;
 }
 
+int search_end(mcf_engine *e, Key *k);
+
 int resident_stop(mcf_engine *e)
 {
     if (!e->resident_running) return MCF_OK;
+    if (e->in_flight == mcf_engine::kResidentSearch || e->in_flight == mcf_engine::kCandSearch) {
+        // a posted search is answered before the grid is told to leave; mcf_engine_search_end then finds the answer waiting
+        Key k;
+        const int rc = search_end(e, &k);
+        if (rc) return rc;
+        e->answered = k;
+        e->in_flight = mcf_engine::kAnswered;
+    }
     e->prev_seq = e->seq;
     e->seq += 1;
     if (e->seq == 0) e->seq = 1;
@@ -810,14 +824,17 @@ void cand_reset_dirty(mcf_engine *e)
     }
 }
 
-int local_search(mcf_engine *e, Key *k)
+// posts / launches the search; search_end collects it.  local_search = both.
+int search_begin(mcf_engine *e)
 {
     if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
+    if (e->in_flight != mcf_engine::kNoSearch) return mcf::fail(MCF_ERR_STATE, "a search is already in flight");
+    Key *const k = &e->answered;
     const double t0 = (double)__rdtsc();
     const bool had = !e->pend_node.empty() || !e->pend_arc.empty();
     if (e->cand_on) {
         // ---- candidate cache: answer from the host when that is provably the scan's answer
-        if (cand_try_host(e, k)) { e->st.searches += 1; e->st.host_decided += 1; return MCF_OK; }
+        if (cand_try_host(e, k)) { e->st.searches += 1; e->st.host_decided += 1; e->in_flight = mcf_engine::kAnswered; return MCF_OK; }
         // the device searches: ship every node / arc touched since its last search, with their current values
         cand_finish_dirty(e);
         e->pend_node.swap(e->dirty_nodes);
@@ -842,7 +859,8 @@ int local_search(mcf_engine *e, Key *k)
         e->launch_ticks += (double)__rdtsc() - t0;
         e->st.searches += 1;
         e->st.arcs_scanned += e->end - e->begin;
-        return cand_collect(e, k);
+        e->in_flight = mcf_engine::kCandSearch;
+        return MCF_OK;
     }
     if (e->resident_ok) {
         // ---- resident mode: post the request into the mailbox, the grid is already running
@@ -866,7 +884,8 @@ int local_search(mcf_engine *e, Key *k)
         e->launch_ticks += (double)__rdtsc() - t0;
         e->st.searches += 1;
         e->st.arcs_scanned += e->end - e->begin;
-        return collect(e, e->res_grid, k);
+        e->in_flight = mcf_engine::kResidentSearch;
+        return MCF_OK;
     }
     e->seq += 1;
     if (e->seq == 0) e->seq = 1;
@@ -883,10 +902,34 @@ int local_search(mcf_engine *e, Key *k)
     }
     e->launch_ticks += (double)__rdtsc() - t0;
     e->st.searches += 1;
-    rc = collect(e, e->grid, k);
-    if (rc) return rc;
-    if (timed) drain_events(e, false);
+    e->in_flight = mcf_engine::kDispatchSearch;
+    e->in_flight_timed = timed;
     return MCF_OK;
+}
+
+int search_end(mcf_engine *e, Key *k)
+{
+    const auto what = e->in_flight;
+    e->in_flight = mcf_engine::kNoSearch;
+    int rc = MCF_OK;
+    switch (what) {
+    case mcf_engine::kNoSearch: return mcf::fail(MCF_ERR_STATE, "no search in flight");
+    case mcf_engine::kAnswered: *k = e->answered; return MCF_OK;
+    case mcf_engine::kCandSearch: return cand_collect(e, k);
+    case mcf_engine::kResidentSearch: return collect(e, e->res_grid, k);
+    case mcf_engine::kDispatchSearch:
+        rc = collect(e, e->grid, k);
+        if (rc) return rc;
+        if (e->in_flight_timed) drain_events(e, false);
+        return MCF_OK;
+    }
+    return rc;
+}
+
+int local_search(mcf_engine *e, Key *k)
+{
+    const int rc = search_begin(e);
+    return rc ? rc : search_end(e, k);
 }
 
 // entering arc, reduced cost and the rule's next_arc from the winning key (host part of the rules)
@@ -1376,6 +1419,23 @@ int mcf_engine_find_entering(mcf_engine *e, int32_t *found, int32_t *arc, int64_
     if (e->begin != 0 || e->end != e->d.search_arc_num) return mcf::fail(MCF_ERR_STATE, "sharded engine: use mcf_engine_find_entering_local / _sharded");
     Key k;
     int rc = local_search(e, &k);
+    if (rc) return rc;
+    resolve_key(e, k, found, arc, reduced_cost);
+    return MCF_OK;
+}
+
+int mcf_engine_search_begin(mcf_engine *e)
+{
+    if (!e) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_search_begin: null argument");
+    if (e->begin != 0 || e->end != e->d.search_arc_num) return mcf::fail(MCF_ERR_STATE, "sharded engine: use mcf_engine_find_entering_local / _sharded");
+    return search_begin(e);
+}
+
+int mcf_engine_search_end(mcf_engine *e, int32_t *found, int32_t *arc, int64_t *reduced_cost)
+{
+    if (!e || !found || !arc) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_search_end: null argument");
+    Key k;
+    const int rc = search_end(e, &k);
     if (rc) return rc;
     resolve_key(e, k, found, arc, reduced_cost);
     return MCF_OK;

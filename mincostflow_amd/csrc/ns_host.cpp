@@ -46,6 +46,9 @@ struct mcf_ns {
     // the pivot being carried out
     int in_arc = -1, join = -1, u_in = -1, v_in = -1, u_out = -1, v_out = -1;
     int64_t delta = 0;
+    int8_t in_state_before = 0;       // State[in_arc] when the pivot started
+    bool out_on_tail_path = false;    // the leaving arc lies on the cycle half that starts at the entering arc's tail
+    bool change = false;              // the pivot changes the basis (find_leaving found a blocking arc)
     // what the last pivot changed (the engine calls of a host)
     int n_state = 0;
     int32_t st_arc[2] = {0, 0};
@@ -176,18 +179,14 @@ bool find_leaving(mcf_ns *s)
     }
     if (side == 1) { s->u_in = first; s->v_in = second; }
     else { s->u_in = second; s->v_in = first; }
+    s->out_on_tail_path = side != 0 && ((side == 1) == (first == s->tail[s->in_arc]));
     return side != 0;
 }
 
-// ---- NS.cs:1012-1040; records the State[] writes the device must see
-void push_flow(mcf_ns *s, bool change)
+// ---- NS.cs:1030-1039, before the flows are touched: the State[] writes of the pivot.  The leaving arc's new state depends on its
+// flow after ChangeFlow (0 -> LOWER, else UPPER), which is its flow now -/+ delta along its half of the cycle (same sums as push_flow).
+void decide_states(mcf_ns *s, bool change)
 {
-    if (s->delta > 0) {
-        const int64_t val = s->state[s->in_arc] * s->delta;
-        s->flow[s->in_arc] += val;
-        for (int u = s->tail[s->in_arc]; u != s->join; u = s->par[u]) s->flow[s->par_arc[u]] -= s->par_dir[u] * val;
-        for (int u = s->head[s->in_arc]; u != s->join; u = s->par[u]) s->flow[s->par_arc[u]] += s->par_dir[u] * val;
-    }
     s->n_state = 0;
     auto set_state = [&](int arc, int8_t v) {
         s->state[arc] = v;
@@ -195,12 +194,27 @@ void push_flow(mcf_ns *s, bool change)
         s->st_val[s->n_state] = v;
         s->n_state++;
     };
+    const int8_t in_state = s->state[s->in_arc];
+    s->in_state_before = in_state;
     if (change) {
-        set_state(s->in_arc, MCF_STATE_TREE);
         const int out = s->par_arc[s->u_out];
-        set_state(out, s->flow[out] == 0 ? MCF_STATE_LOWER : MCF_STATE_UPPER);
+        const int64_t val = in_state * s->delta;
+        const int64_t after = s->out_on_tail_path ? s->flow[out] - s->par_dir[s->u_out] * val : s->flow[out] + s->par_dir[s->u_out] * val;
+        set_state(s->in_arc, MCF_STATE_TREE);
+        set_state(out, after == 0 ? MCF_STATE_LOWER : MCF_STATE_UPPER);
     } else {
-        set_state(s->in_arc, (int8_t)-s->state[s->in_arc]);
+        set_state(s->in_arc, (int8_t)-in_state);
+    }
+}
+
+// ---- NS.cs:1012-1029: the flow change around the cycle (old tree; nothing the device needs)
+void push_flow(mcf_ns *s)
+{
+    if (s->delta > 0) {
+        const int64_t val = s->in_state_before * s->delta;
+        s->flow[s->in_arc] += val;
+        for (int u = s->tail[s->in_arc]; u != s->join; u = s->par[u]) s->flow[s->par_arc[u]] -= s->par_dir[u] * val;
+        for (int u = s->head[s->in_arc]; u != s->join; u = s->par[u]) s->flow[s->par_arc[u]] += s->par_dir[u] * val;
     }
 }
 
@@ -290,9 +304,11 @@ constexpr int kWalkPiece = 4096;   // a big walk hands its nodes to the engine i
 
 void shift_potentials(mcf_ns *s)
 {
-    s->sigma = s->pi[s->v_in] - s->pi[s->u_in] - s->par_dir[s->u_in] * s->cost[s->in_arc];
+    // runs BEFORE the re-hanging: the nodes that move are the subtree of u_out as it hangs now, and u_in's new parent direction is known
+    const int8_t dir_in = s->u_in == s->tail[s->in_arc] ? kUp : kDown;
+    s->sigma = s->pi[s->v_in] - s->pi[s->u_in] - dir_in * s->cost[s->in_arc];
     const int64_t sigma = s->sigma;
-    const int count = s->sub[s->u_in];
+    const int count = s->sub[s->u_out];
     s->moved_n = count;
     int32_t *const nodes = s->moved.data();
     int64_t *const vals = s->moved_val.data();
@@ -300,7 +316,7 @@ void shift_potentials(mcf_ns *s)
     const int32_t *const nxt = s->nxt.data(), *const prv = s->prv.data();
     if (count < kWalkHintMin) {
         int lo = 0, hi = count - 1;
-        int a = s->u_in, b = s->fin[s->u_in];
+        int a = s->u_out, b = s->fin[s->u_out];
         while (lo < hi) {
             nodes[lo] = a; vals[lo] = (pi[a] += sigma); a = nxt[a]; ++lo;
             nodes[hi] = b; vals[hi] = (pi[b] += sigma); b = prv[b]; --hi;
@@ -309,7 +325,7 @@ void shift_potentials(mcf_ns *s)
         return;
     }
     int32_t *const follow = s->follow.data();
-    int a = s->u_in;
+    int a = s->u_out;
     for (int i = 0; i < count; ++i) {
         const int h = follow[a];
         __builtin_prefetch(&nxt[h]);
@@ -327,29 +343,45 @@ void shift_potentials(mcf_ns *s)
     }
 }
 
-// one pivot with a given entering arc; returns true when the problem is found unbounded (NS.cs:321-325)
-bool pivot(mcf_ns *s, int arc, double *t_tree, double *t_pot)
+// One pivot with a given entering arc, in two halves.  pivot_front does what the next search depends on -- the cycle, the State[] writes and
+// the potentials of the subtree that is about to move (handed to the engine as they arise) -- and returns true when the problem is
+// found unbounded (NS.cs:321-325).  pivot_back does the rest (flows around the cycle, re-hanging the subtree): the solve loop runs it
+// while the device is already searching.
+bool pivot_front(mcf_ns *s, int arc, double *t_pot)
 {
     s->in_arc = arc;
     s->moved_n = 0;
     s->moved_sent = 0;
     s->sigma = 0;
     find_join(s);
-    const bool change = find_leaving(s);
+    const bool change = s->change = find_leaving(s);
     if (!change && s->delta == 0) return true;
-    push_flow(s, change);
+    decide_states(s, change);
     // the engine hears about the state writes before any piece of the potential list (the pieces may start travelling at once)
     if (s->hand_over && !s->engine_rc) s->engine_rc = mcf_engine_patch_state(s->engine, s->n_state, s->st_arc, s->st_val);
     if (s->delta == 0) s->metrics.degenerate_pivots++;
     if (change) {
-        const double t0 = ticks();
-        rehang_subtree(s);
         const double t1 = ticks();
         shift_potentials(s);
-        const double t2 = ticks();
-        if (t_tree) *t_tree += t1 - t0;
-        if (t_pot) *t_pot += t2 - t1;
+        if (t_pot) *t_pot += ticks() - t1;
     }
+    return false;
+}
+
+void pivot_back(mcf_ns *s, double *t_tree)
+{
+    push_flow(s);
+    if (s->change) {
+        const double t0 = ticks();
+        rehang_subtree(s);
+        if (t_tree) *t_tree += ticks() - t0;
+    }
+}
+
+bool pivot(mcf_ns *s, int arc, double *t_tree, double *t_pot)
+{
+    if (pivot_front(s, arc, t_pot)) return true;
+    pivot_back(s, t_tree);
     return false;
 }
 
@@ -616,11 +648,15 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     double t_search = 0, t_tree = 0, t_pot = 0;
     s->hand_over = true;
     s->engine_rc = 0;
+    // The search for pivot k+1 is posted as soon as the device has what it depends on (State[] writes, potentials); the rest of pivot k
+    // (flows around the cycle, re-hanging the subtree) runs while the device is searching.  Sharded engines search in one blocking
+    // call (the RCCL exchange), so for them the two halves simply follow each other.
+    const bool split = !s->sharded;
+    if (split) { rc = mcf_engine_search_begin(s->engine); if (rc) return rc; }
     for (;;) {
         const double t0 = ticks();
         int32_t found = 0, arc = -1;
-        rc = s->sharded ? mcf_engine_find_entering_sharded(s->engine, &found, &arc, nullptr)
-                        : mcf_engine_find_entering(s->engine, &found, &arc, nullptr);
+        rc = split ? mcf_engine_search_end(s->engine, &found, &arc, nullptr) : mcf_engine_find_entering_sharded(s->engine, &found, &arc, nullptr);
         t_search += ticks() - t0;
         if (rc) return rc;
         if (!found) break;
@@ -628,13 +664,15 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         ++it;
         if (it > max_iter) { s->status = MCF_INFEASIBLE; break; }                          // NS.cs:311-317
         if (s->pivot_limit && it > s->pivot_limit) { --it; limited = true; break; }
-        if (pivot(s, arc, &t_tree, &t_pot)) { s->status = MCF_UNBOUNDED; break; }
+        if (pivot_front(s, arc, &t_pot)) { s->status = MCF_UNBOUNDED; break; }
         const double t1 = ticks();
         rc = s->engine_rc;
         if (!rc && s->moved_n > s->moved_sent)
             rc = mcf_engine_append_potential(s->engine, (int32_t)(s->moved_n - s->moved_sent), s->moved.data() + s->moved_sent, s->moved_val.data() + s->moved_sent);
+        if (!rc && split) rc = mcf_engine_search_begin(s->engine);
         t_pot += ticks() - t1;
         if (rc) return rc;
+        pivot_back(s, &t_tree);
         s->metrics.potential_nodes += (int64_t)s->moved_n;
     }
     s->hand_over = false;

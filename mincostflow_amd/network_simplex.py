@@ -336,6 +336,14 @@ class PivotEngine:
         L.check(L.lib().mcf_engine_find_entering(self._h, C.byref(f), C.byref(a), C.byref(c)))
         return bool(f.value), a.value, c.value
 
+    def search_begin(self):
+        L.check(L.lib().mcf_engine_search_begin(self._h))
+
+    def search_end(self):
+        f, a, c = C.c_int32(), C.c_int32(), C.c_int64()
+        L.check(L.lib().mcf_engine_search_end(self._h, C.byref(f), C.byref(a), C.byref(c)))
+        return bool(f.value), a.value, c.value
+
     def find_entering_local(self) -> L.Candidate:
         c = L.Candidate()
         L.check(L.lib().mcf_engine_find_entering_local(self._h, C.byref(c)))

@@ -561,3 +561,37 @@ def test_potential_lists_that_arrive_in_pieces(mode, m_s, n):
             eng.append_potential(nodes[lo:hi], a["pi"][nodes[lo:hi]])
     assert np.array_equal(eng.download_pi(), a["pi"])
     assert np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+def test_search_in_two_halves(mode):
+    """mcf_engine_search_begin / _end: the answer is the blocking call's; patches queued while a search is in flight belong to the next one;
+    parking the engine (or reading its statistics) in between keeps the answer."""
+    rng = np.random.default_rng(606)
+    m_s, n = 120007, 30000
+    a = _random_soa(rng, m_s, n, 4, 12)
+    eng = M.PivotEngine(n, len(a["src"]), m_s, rule=M.PivotRule.BestEligible, optimized=True, flags=mode)
+    eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+    with pytest.raises(M.McfError):
+        eng.search_end()                                  # nothing in flight
+    for it in range(10):
+        want = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+        eng.search_begin()
+        with pytest.raises(M.McfError):
+            eng.search_begin()                            # one at a time
+        # queued now, seen by the NEXT search only
+        arcs = rng.choice(m_s, size=2, replace=False).astype(np.int32); vals = rng.integers(-1, 2, 2).astype(np.int8)
+        nodes = rng.choice(n, size=int(rng.choice([1, 30, 6000])), replace=False).astype(np.int32)
+        eng.patch_state(arcs, vals)
+        if it % 3 == 1:
+            eng.park()
+        if it % 3 == 2:
+            eng.stats()
+        f, e, c = eng.search_end()
+        assert f == want[0] and (not f or (e, c) == (want[1], want[2])), (it, e, want)
+        a["state"][arcs] = vals
+        a["pi"][nodes] -= 3
+        eng.append_potential(nodes, a["pi"][nodes])
+    assert np.array_equal(eng.download_pi(), a["pi"])
+    assert np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
