@@ -9,9 +9,12 @@ Workload (config.workload): BASELINE.json configs[2] = NETGEN-like 100 000 nodes
 Solve() pivot loop of that instance with the SoA arc arrays and potentials ALREADY resident in HBM (mcf_ns_prepare runs
 before the timed region); value = pivots performed by all ranks / max-over-ranks wall time of the K steps.
 
-N > 1: the path shards by independent instances (one solve per GPU, seed + rank): no data-path collective, "scaling": "weak".
-The RCCL MINLOC exchange that shards ONE instance's arcs over the GPUs (BASELINE.json configs[4]) is timed separately with
---sharded-pivots (a bounded number of pivots of the 1M-node / 8M-arc instance) and reported under "sharded".
+N > 1 (`"scaling": "weak"`): `value` keeps the N = 1 metric and workload -- one config-3 solve per GPU (seed + rank), no data-path
+collective -- so the driver's per-N values are comparable.  The line ALSO carries, by default, the path BASELINE.json configs[4]
+names: ONE 1M-node / 8M-arc instance with its arcs sharded over the ranks and a MINLOC exchange per pivot (block "sharded":
+ranks as seen by the communicator, us per pivot for the RCCL all-gather exchange and for the shared-memory host exchange, and the
+single-GPU figure for the same pivots).  Without a launcher `--gpus N` starts the N ranks itself (before anything touches a GPU);
+a WORLD_SIZE that differs from --gpus is refused, and `n_gpus` is always the number of ranks that ran.
 
 The JSON line also carries
   roofline      dominant kernel = the resident entering-arc scan grid (one dispatch serves every pivot of a solve through a mailbox).
@@ -36,6 +39,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
 SEED = 13502460
+TRAFFIC_FILE = "traffic_r01.json"   # PMC FETCH_SIZE of a separate rocprofv3 --pmc pass (gpurun refuses --pmc beside tracing)
 
 
 def parse():
@@ -47,8 +51,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
     ap.add_argument("--no-validator", action="store_true", help="skip the SolutionValidator measurement")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the compact config-2 / config-4 blocks")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline sample")
-    ap.add_argument("--sharded-pivots", type=int, default=0, help="N>1: also time this many pivots of config 5 sharded over RCCL")
+    ap.add_argument("--sharded-pivots", type=int, default=-1, help="N>1: pivots of config 5 timed with the arcs sharded over the ranks (-1 = 2000 when N > 1, 0 = skip)")
     ap.add_argument("--dispatch", action="store_true", help="one scan dispatch per search instead of the resident grid")
     ap.add_argument("--concurrent", type=int, default=4, help="extra measurement: this many independent solves at once on the GPU (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo: rehearsals on one GPU)")
@@ -67,11 +72,23 @@ def workload(name, seed):
             "NETGEN-like 100k nodes / 300k arcs, Best-Eligible full-arc scan, int64")
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(g, rule, budget_s):
-    """Oracle (C port of the reference, EnableOptimizedPivot semantics), same instance and rule, one core."""
+    """Oracle (C port of the reference, EnableOptimizedPivot semantics), same instance and rule, one core; with the reference's three
+    phase buckets (SolverMetrics: pivot search / tree update / potential update)."""
     from oracle import ns_oracle as O
     p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
     o = O.Oracle(p, O.SEM_CSHARP_OPT, {0: O.RULE_FIRST, 1: O.RULE_BEST, 2: O.RULE_BLOCK}[rule])
+    o.enable_timing()
     o.init()
     done, ended, t0 = 0, False, time.perf_counter()
     chunk = 256
@@ -80,9 +97,86 @@ def cpu_baseline(g, rule, budget_s):
         done += k
         chunk = min(chunk * 2, 1 << 16)
     dt = time.perf_counter() - t0
+    ph = o.phase_us()
     sample = (f"whole solve ({done} pivots)" if ended else f"first {done} pivots of the same solve") + f", {dt:.1f} s of CPU work"
     return {"value": done / dt, "unit": "pivots/s", "cores": 1, "kind": "port", "sample": sample,
-            "host_cores_available": os.cpu_count(), "us_per_pivot": dt / max(done, 1) * 1e6}
+            "host_cores_available": os.cpu_count(), "host_cpu": cpu_model(), "us_per_pivot": dt / max(done, 1) * 1e6,
+            "phase_us_per_pivot": {"pivot_search": ph[0] / max(done, 1), "tree_update": ph[1] / max(done, 1), "potential_update": ph[2] / max(done, 1)},
+            "solve_ms_if_whole": dt * 1e3 if ended else None,
+            "not_timed": "LEMON (needs its CMake-generated config.h: unbuildable here) and the C# reference (no .NET toolchain in the image)"}
+
+
+def other_config(M, name, local_rank, cpu_seconds):
+    """BASELINE.json configs[1] / configs[3] in one compact block: one warm solve on the GPU, the same-rule CPU port beside it."""
+    g, rule, width, desc = workload(name, SEED)
+    def solve():
+        ns = M.NetworkSimplex.from_problem(g).set_pivot_rule(rule).enable_optimized_pivot(True).set_device(local_rank, width, 0, 0).prepare()
+        assert ns.solve() == M.SolverStatus.Optimal
+        return ns
+    solve()
+    ns = solve()
+    m = ns.get_metrics(); it = max(m["iterations"], 1)
+    out = {"workload": desc, "pivots": m["iterations"], "solve_ms": m["loop_us"] / 1e3, "pivots_per_s": it / (m["loop_us"] / 1e6),
+           "us_per_pivot": m["loop_us"] / it, "pivot_search_us": m["pivot_search_us"] / it, "total_cost": ns.get_total_cost()}
+    del ns
+    if cpu_seconds > 0:
+        b = cpu_baseline(g, rule, cpu_seconds)
+        out["cpu_same_rule"] = {"pivots_per_s": b["value"], "us_per_pivot": b["us_per_pivot"], "sample": b["sample"], "cores": 1, "kind": "port"}
+        out["gpu_over_cpu_per_pivot"] = b["us_per_pivot"] / out["us_per_pivot"]
+    return out
+
+
+def sharded_leg(M, torch, dist, args, rank, world, dev, barrier, red_dev):
+    """BASELINE.json configs[4]: ONE NETGEN-like 1M-node / 8M-arc instance, arcs sharded over the ranks, one MINLOC exchange per pivot.
+    Every rank runs the same host loop on its own shard; timed: the first --sharded-pivots pivots, max over ranks."""
+    import numpy as np
+    P = args.sharded_pivots
+    g5 = M.netgen_like(SEED, 1_000_000, 8_000_000, 1000, 1000)
+
+    def run(configure):
+        ns5 = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).set_device(dev, 64, 0, 0)
+        configure(ns5)
+        ns5.set_pivot_limit(P).record_trace(P).prepare()
+        barrier()                                  # also: every rank has opened the exchange before the first pivot
+        ts = time.perf_counter()
+        ns5.solve()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        m5 = ns5.get_metrics()
+        return float(t.item()), m5, ns5.trace()
+
+    out = {"workload": "NETGEN-like 1M nodes / 8M arcs, Best Eligible, int64, arcs sharded over the ranks (contiguous ranges, potentials replicated)",
+           "ranks": world, "pivots_timed": P, "search_arcs": 9_000_000, "variants": {}}
+    port = os.environ.get("MASTER_PORT", "0")
+    sec, m5, tr_host = run(lambda ns: ns.set_sharding_host(f"/mcf_bench_{port}_{os.getppid()}", rank, world))
+    out["variants"]["host_exchange"] = {"exchange": "16-byte records through POSIX shared memory (mcf_exchange_all_gather), resident or dispatch scan per shard",
+                                        "ranks": world, "pivots": m5["iterations"], "seconds": sec, "us_per_pivot": sec / max(m5["iterations"], 1) * 1e6,
+                                        "pivots_per_s": m5["iterations"] / sec, "shard_engine_resident": bool(m5["engine"]["resident"])}
+    same = True
+    if args.backend == "nccl":
+        ident = torch.from_numpy(M.comm_unique_id() if rank == 0 else np.zeros(128, "uint8")).cuda()
+        dist.broadcast(ident, src=0)
+        sec, m5, tr_rccl = run(lambda ns: ns.set_sharding(ident.cpu().numpy(), rank, world))
+        out["variants"]["rccl_all_gather"] = {"exchange": "ncclAllGather of 16 B per rank on the engine's stream + local MINLOC, every pivot",
+                                              "ranks": int(m5["engine"]["comm_ranks"]), "pivots": m5["iterations"], "seconds": sec,
+                                              "us_per_pivot": sec / max(m5["iterations"], 1) * 1e6, "pivots_per_s": m5["iterations"] / sec}
+        same = same and bool(np.array_equal(tr_rccl, tr_host))
+    # the same pivots on ONE GPU (rank 0 alone, un-sharded), the figure the sharded ones have to beat
+    if rank == 0:
+        ns1 = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).set_device(dev, 64, 0, 0)
+        ns1.set_pivot_limit(P).record_trace(P).prepare()
+        ts = time.perf_counter()
+        ns1.solve()
+        sec1 = time.perf_counter() - ts
+        m1 = ns1.get_metrics()
+        out["single_gpu_same_pivots"] = {"pivots": m1["iterations"], "seconds": sec1, "us_per_pivot": sec1 / max(m1["iterations"], 1) * 1e6}
+        same = same and bool(np.array_equal(ns1.trace(), tr_host))
+        del ns1
+    barrier()
+    out["identical_pivot_sequence"] = same
+    return out
 
 
 def microbench():
@@ -224,18 +318,35 @@ def pin_near_gpu(dev):
     return None
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the N ranks ourselves.  Nothing has touched the GPU yet (no torch.cuda / HIP call, no exec of an initialised process).
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to label a {world}-rank run as {args.gpus} GPUs")
+    if args.sharded_pivots < 0:
+        args.sharded_pivots = 2000 if world > 1 else 0
 
     import torch
     import mincostflow_amd as M
     if M.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: libmcf_hip.so has no CPU path")
+    if world > M.device_count() and args.backend == "nccl":
+        raise SystemExit(f"{world} ranks but {M.device_count()} GPU(s): one rank per GPU (rehearse more ranks on one GPU with --backend gloo)")
     dev = local_rank % M.device_count()          # one rank per GPU; ranks only share a GPU in gloo rehearsals
     dist = None
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
@@ -292,25 +403,8 @@ def main():
         pivots_all = pivots
 
     sharded = None
-    if dist is not None and args.sharded_pivots > 0 and args.backend == "nccl":
-        # BASELINE.json configs[4]: ONE instance, arcs sharded over the ranks, RCCL all-gather MINLOC per pivot
-        g5 = M.netgen_like(SEED, 1_000_000, 8_000_000, 1000, 1000)
-        ident = torch.from_numpy(M.comm_unique_id() if rank == 0 else __import__("numpy").zeros(128, "uint8")).cuda()
-        dist.broadcast(ident, src=0)
-        ns5 = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True)
-        ns5.set_device(dev, 64, 0, 0).set_sharding(ident.cpu().numpy(), rank, world).set_pivot_limit(args.sharded_pivots).prepare()
-        barrier()
-        ts = time.perf_counter()
-        ns5.solve()
-        torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        m5 = ns5.get_metrics()
-        sharded = {"workload": "NETGEN-like 1M nodes / 8M arcs, Best Eligible, int64, arcs sharded over the ranks",
-                   "exchange": "ncclAllGather of 16 B per rank + local MINLOC, every pivot", "ranks": world, "pivots": m5["iterations"],
-                   "seconds": float(t.item()), "us_per_pivot": float(t.item()) / max(m5["iterations"], 1) * 1e6,
-                   "pivots_per_s": m5["iterations"] / float(t.item())}
-        del ns5, g5
+    if dist is not None and args.sharded_pivots > 0:
+        sharded = sharded_leg(M, torch, dist, args, rank, world, dev, barrier, red_dev)
 
     if rank != 0:
         if dist is not None:
@@ -355,7 +449,7 @@ def main():
                               "frac": bytes_per_scan / d_avg / HBM_PEAK_GBS,
                               "what": "scan_kernel as one dispatch per search, timed alone with HIP events; an EMPTY dispatch measures ~4 us by this method"}
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")            # separate rocprofv3 --pmc passes, see profiles/README.md
+    tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)                  # separate rocprofv3 --pmc passes, see profiles/README.md
     if os.path.exists(tpath) and args.workload == "config3":
         tj = json.load(open(tpath))
         if resident:
@@ -367,7 +461,7 @@ def main():
         "metric": "pivots/sec + solve ms, NETGEN 100k-node/300k-arc; arc-scan GB/s vs HBM peak",
         "value": pivots_all / elapsed_max,
         "unit": "pivots/s",
-        "n_gpus": args.gpus,
+        "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed_max / args.steps * 1e3,
@@ -378,7 +472,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": desc, "instance": f"netgen_like(seed={SEED}+rank)" if args.workload != "config4" else "assignment(seed 42)",
                    "pivot_rule": {0: "FirstEligible", 1: "BestEligible", 2: "BlockSearch"}[rule], "semantics": "EnableOptimizedPivot(true)",
-                   "search_arcs": mets[0]["search_arc_num"], "parallelism": "1 solve per GPU" if args.gpus > 1 else "1 GPU", "host_thread_numa_node": numa},
+                   "search_arcs": mets[0]["search_arc_num"], "parallelism": f"{world} ranks, 1 solve per GPU" if world > 1 else "1 GPU", "host_thread_numa_node": numa},
         "solve_ms": sum(m["loop_us"] for m in mets) / len(mets) / 1e3,
         "solve_ms_incl_setup_and_upload": sum(m["total_solve_us"] for m in mets) / len(mets) / 1e3,
         "pivots_per_solve": pivots / len(mets),
@@ -388,7 +482,9 @@ def main():
         "engine": {"mode": "resident grid + BAR mailbox" if resident else "one dispatch per search", "scan_workgroups": e[0]["scan_workgroups"], "inline_update_share": sum(x["inline_updates"] for x in e) / max(pivots, 1),
                    "separate_update_launches": sum(x["update_launches"] for x in e), "avg_subtree_nodes": per("potential_nodes")},
         "roofline": dict({"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": bytes_per_launch,
+                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                          "traffic_source": f"profiles/{TRAFFIC_FILE} (separate rocprofv3 --pmc FETCH_SIZE pass of the same workload, not measured in this run)" if traffic is not None else None,
+                          "bytes_per_launch": bytes_per_launch,
                           "note": "7.6 MB per scan lives in L2 / Infinity Cache and the per-pivot cost is host <-> device latency, not bandwidth; "
                                   "scan_microbench holds the bandwidth-bound sizes"}, **extra),
     }
@@ -429,6 +525,8 @@ def main():
         if rule != M.PivotRule.BlockSearch:
             blk = cpu_baseline(g, M.PivotRule.BlockSearch, args.cpu_seconds)
             line["cpu_baseline_block_search"] = blk       # the reference's default rule, for the cross-rule comparison
+    if not args.no_other_configs and args.gpus == 1 and args.workload == "config3":
+        line["other_configs"] = {c: other_config(M, c, local_rank, 0 if args.no_cpu_baseline else min(args.cpu_seconds, 8.0)) for c in ("config2", "config4")}
     if not args.no_microbench and args.gpus == 1:
         line["scan_microbench"] = microbench()
         line["hbm_measured"] = hbm_probe()

@@ -95,6 +95,8 @@ typedef struct mcf_engine_desc {
     int32_t shard_begin, shard_end;
     int32_t scan_workgroups;  /* 0 = auto; otherwise the grid of the scan kernel */
     int32_t flags;            /* MCF_ENGINE_* */
+    int32_t resident_workgroups;  /* 0 = auto (one workgroup per CU, at most 256); otherwise a cap on the resident grid: engines that share
+                                     a device (arc shards rehearsed on one GPU) must all be co-resident to answer */
 } mcf_engine_desc;
 
 #define MCF_ENGINE_SAMPLE_KERNEL_TIME 1   /* time every 16th scan dispatch with HIP events */
@@ -112,6 +114,38 @@ typedef struct mcf_engine_desc {
 #define MCF_ENGINE_DISPATCH 16            /* one scan dispatch per search.  Also what an engine falls back to when it is sharded, when
                                              kernel timing flags are set, or when the platform has no host-writable VRAM.
                                              The environment variable MCF_HIP_RESIDENT=0/1 overrides the choice. */
+
+/* The part of OptimizationConfig (Algorithms/OptimizationTypes.cs:9-38) that the plain BlockSearchPivot consumes
+ * (NS.cs:1304-1337 initial size, :1400-1438 adaptive size).  The OPTIMIZED flavour ignores it (BSPO.cs:27-28), and so
+ * do the other rules.  Flag values are the reference's OptimizationFlags. */
+#define MCF_OPT_NONE 0
+#define MCF_OPT_ADAPTIVE_BLOCK_SIZE 1       /* OptimizationFlags.AdaptiveBlockSize */
+#define MCF_OPT_SMALL_BLOCKS_FOR_DENSE 2    /* OptimizationFlags.SmallBlocksForDense */
+#define MCF_OPT_REDUCED_COST_CACHING 4      /* OptimizationFlags.ReducedCostCaching: recorded, never acted on */
+typedef struct mcf_block_config {
+    int32_t flags;                          /* MCF_OPT_* */
+    int32_t min_block_size;                 /* MinBlockSize                (default 25)    */
+    int32_t max_block_size;                 /* MaxBlockSize                (default 100)   */
+    int32_t consecutive_hits_before_adapt;  /* ConsecutiveHitsBeforeAdapt  (default 3)     */
+    double min_block_size_ratio;            /* MinBlockSizeRatio           (default 0.125) */
+    double block_size_growth_factor;        /* BlockSizeGrowthFactor       (default 1.2)   */
+    double block_size_shrink_factor;        /* BlockSizeShrinkFactor       (default 0.8)   */
+    double low_hit_rate_threshold;          /* LowHitRateThreshold         (default 0.05)  */
+    double high_hit_rate_threshold;         /* HighHitRateThreshold        (default 0.3)   */
+} mcf_block_config;
+/* new OptimizationConfig() (OptimizationTypes.cs:24-38) */
+MCF_API void mcf_block_config_default(mcf_block_config *c);
+/* OptimizationSelector.SelectConfiguration(ProblemAnalyzer.Analyze(graph)) (Analysis/OptimizationSelector.cs:14-95,
+ * Lemon/ProblemAnalyzer.cs:21-106) restricted to the fields above: what `new NetworkSimplex(g).Solve()` configures
+ * itself with by default (NS.cs:90, :237-250).  Needs the original graph only (node count, arc end points). */
+MCF_API int mcf_block_config_auto(mcf_block_config *c, int32_t node_count, int32_t arc_count, const int32_t *source, const int32_t *target);
+/* The two pieces of BlockSearchPivot that act on the configuration, as pure functions (the engine calls them; a host that keeps
+ * its own rule state may too).  mcf_block_initial_size: the constructor, NS.cs:1304-1336 -- *block_size = _blockSize,
+ * *dynamic_min = _dynamicMinBlockSize; graph_node_count = the reference's _nodeCount (no artificial root).
+ * mcf_block_adapt: NS.cs:1400-1438 after a successful search that examined arcs_checked arcs; counters[0] = _consecutiveLowHits,
+ * counters[1] = _consecutiveHighHits. */
+MCF_API int mcf_block_initial_size(const mcf_block_config *c, int32_t search_arc_num, int32_t graph_node_count, int32_t *block_size, int32_t *dynamic_min);
+MCF_API int mcf_block_adapt(const mcf_block_config *c, int32_t dynamic_min, int64_t arcs_checked, int32_t *block_size, int32_t counters[2]);
 
 /* replaces the constructor of OptimizedPivotWrapper (NS.cs:1677-1697) */
 MCF_API int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc);
@@ -159,6 +193,8 @@ typedef struct mcf_candidate {
     int32_t arc;            /* -1 when none */
 } mcf_candidate;
 MCF_API int mcf_engine_find_entering_local(mcf_engine *e, mcf_candidate *out);
+/* second half of a search posted with mcf_engine_search_begin on a sharded engine (the first half is the same call for every engine) */
+MCF_API int mcf_engine_search_end_local(mcf_engine *e, mcf_candidate *out);
 /* Picks the global winner among `count` candidates (one per shard) with the rule's exact tie-breaking and advances
  * next_arc on THIS engine (every rank calls it with the same gathered array).  *found / *arc as above. */
 MCF_API int mcf_engine_resolve(mcf_engine *e, int32_t count, const mcf_candidate *all, int32_t *found,
@@ -175,6 +211,11 @@ MCF_API int mcf_engine_park(mcf_engine *e);
 MCF_API int mcf_engine_get_next_arc(mcf_engine *e, int32_t *next_arc);
 MCF_API int mcf_engine_set_next_arc(mcf_engine *e, int32_t next_arc);
 MCF_API int mcf_engine_get_block_size(mcf_engine *e, int32_t *block_size);
+/* Block Search, PLAIN semantics: size the blocks like `new BlockSearchPivot(ns)` with this configuration (NS.cs:1304-1337;
+ * graph_node_count = the reference's _nodeCount, i.e. WITHOUT the artificial root) and, with MCF_OPT_ADAPTIVE_BLOCK_SIZE, adapt
+ * the size after every successful search like NS.cs:1400-1438.  The size travels with every search request.  Call before the
+ * first search; a block_size given at creation (desc.block_size > 0) stays the initial size. */
+MCF_API int mcf_engine_set_block_config(mcf_engine *e, const mcf_block_config *c, int32_t graph_node_count);
 
 /* parity checks */
 MCF_API int mcf_engine_download_pi(mcf_engine *e, int64_t *pi_out /* [node_count] */);
@@ -200,6 +241,12 @@ typedef struct mcf_engine_stats {
     double resident_kernel_ns;    /* HIP-event residency time of those dispatches */
     int64_t candidates;           /* 1 when the candidate cache is active */
     int64_t host_decided;         /* searches answered from the candidate list without a device request */
+    int64_t arcs_checked;         /* arcs the REFERENCE's loop would have examined for the same searches: what it adds to
+                                     SolverMetrics.TotalArcsChecked (NS.cs:286-290).  Only the plain BlockSearchPivot counts
+                                     (NS.cs:1349-1350, :1371-1372); every other finder leaves it at 0, and so does this */
+    int32_t initial_block_size, current_block_size;
+    int32_t comm_ranks;           /* ranks of the RCCL communicator as ncclCommCount reports them (0: no communicator) */
+    int32_t reserved;
 } mcf_engine_stats;
 MCF_API int mcf_engine_get_stats(mcf_engine *e, mcf_engine_stats *out);
 MCF_API int mcf_engine_reset_stats(mcf_engine *e);
@@ -216,6 +263,15 @@ MCF_API int mcf_comm_unique_id(uint8_t id_out[128]);
 MCF_API int mcf_engine_comm_init(mcf_engine *e, const uint8_t id[128], int32_t rank, int32_t world);
 /* find_entering_local + all-gather + resolve in one call */
 MCF_API int mcf_engine_find_entering_sharded(mcf_engine *e, int32_t *found, int32_t *arc, int64_t *reduced_cost);
+
+/* Host exchange for sharded engines ("per-GPU result slots reduced by the host"): the ranks of ONE node put their
+ * 16-byte candidates into POSIX shared memory and read each other's -- an all-gather without a collective library, a fraction of a
+ * microsecond per pivot where one ncclAllGather of 16 bytes costs tens.  name: the same on every rank, "/something" (shm_open);
+ * all ranks must have returned from mcf_exchange_open (any barrier of the caller's) before the first mcf_exchange_all_gather. */
+typedef struct mcf_exchange mcf_exchange;
+MCF_API int mcf_exchange_open(mcf_exchange **out, const char *name, int32_t rank, int32_t world);
+MCF_API void mcf_exchange_close(mcf_exchange *x);
+MCF_API int mcf_exchange_all_gather(mcf_exchange *x, const mcf_candidate *mine, mcf_candidate *all /* [world] */);
 
 /* ------------------------------------------------------------------------------------------------
  * (2) Host driver: NetworkSimplex restated (mirror of the public surface of NS.cs)
@@ -234,11 +290,23 @@ MCF_API int mcf_ns_set_problem(mcf_ns *s, const int64_t *lower, const int64_t *u
 MCF_API int mcf_ns_set_supply_type(mcf_ns *s, int32_t type);                               /* NS.cs:197-201 */
 MCF_API int mcf_ns_set_pivot_rule(mcf_ns *s, int32_t rule);                                /* NS.cs:206-210 */
 MCF_API int mcf_ns_enable_optimized_pivot(mcf_ns *s, int32_t enable);                      /* NS.cs:532-535 */
+/* SetOptimizationConfig (NS.cs:557-561; switches auto-configuration off), EnableOptimizations (NS.cs:549-552),
+ * SetAutoConfiguration (NS.cs:567-570; the reference's default is ON, and so is this library's) */
+MCF_API int mcf_ns_set_optimization_config(mcf_ns *s, const mcf_block_config *config);
+MCF_API int mcf_ns_enable_optimizations(mcf_ns *s, int32_t flags);
+MCF_API int mcf_ns_set_auto_configuration(mcf_ns *s, int32_t enable);
 /* device-side options that have no counterpart in the reference */
 MCF_API int mcf_ns_set_device(mcf_ns *s, int32_t device, int32_t int_width /* 32, 64, 0 = narrowest that is safe */,
                               int32_t block_size /* 0 = reference default */, int32_t engine_flags);
 /* shard the arc scan over `world` ranks exchanging over RCCL (every rank runs the same host loop) */
 MCF_API int mcf_ns_set_sharding(mcf_ns *s, const uint8_t nccl_id[128], int32_t rank, int32_t world);
+
+/* the same sharding with the candidates exchanged through shared memory (mcf_exchange_*) instead of RCCL: every rank runs the same
+ * host loop, its engine keeps its arc shard in a resident grid; exchange_name as for mcf_exchange_open */
+MCF_API int mcf_ns_set_sharding_host(mcf_ns *s, const char *exchange_name, int32_t rank, int32_t world);
+/* the same sharding inside ONE process: `shards` engines, one per entry of devices[] (entries may repeat: arc shards rehearsed on fewer
+ * GPUs), driven by this solver's single host thread, which posts every search to all of them and reduces their answers itself */
+MCF_API int mcf_ns_set_shard_group(mcf_ns *s, int32_t shards, const int32_t *devices);
 
 /* Optional: everything Solve() does before its pivot loop (CheckBounds, TransformToStandardForm, Initialize, creating the
  * engine and copying the SoA arrays into HBM).  mcf_ns_solve() calls it when the caller has not. */
@@ -262,6 +330,17 @@ typedef struct mcf_ns_metrics {
     int32_t search_arc_num, block_size, int_width, reserved;
     int64_t degenerate_pivots, potential_nodes;
     mcf_engine_stats engine;
+    /* the remaining SolverMetrics fields (OptimizationTypes.cs:53-59), filled like NS.cs:262-270, :344-357 */
+    int32_t initial_block_size, final_block_size;      /* Block Search, plain flavour; 0 otherwise (NS.cs:263-270, :348-355) */
+    int64_t total_arcs_checked;                        /* see mcf_engine_stats.arcs_checked */
+    double average_arcs_checked_per_pivot;
+    int32_t baseline_iterations;                       /* (int)(sqrt(m_s) * n * 0.5), NS.cs:276 */
+    int32_t config_flags;                              /* MCF_OPT_* in force during the solve (auto-configured or set) */
+    double iteration_ratio;
+    int32_t reference_selects_cached_pivot;            /* 1: with this configuration the reference would run CachedBlockSearchPivot
+                                                          (NS.cs:855-883), which this library does not reproduce (SURVEY.md 8a row a8:
+                                                          documented failure, stale cache entries); the plain Block Search ran instead */
+    int32_t reserved2;
 } mcf_ns_metrics;
 MCF_API int mcf_ns_get_metrics(mcf_ns *s, mcf_ns_metrics *out);                            /* NS.cs:584-587 */
 /* measurement aid: Solve() stops after max_pivots pivots and reports MCF_NOT_SOLVED (0 = no limit) */

@@ -33,7 +33,7 @@ class McfError(RuntimeError):
 
 class EngineDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("node_count", "arc_capacity", "search_arc_num", "int_width", "rule", "semantics",
-                                         "block_size", "device", "shard_begin", "shard_end", "scan_workgroups", "flags")]
+                                         "block_size", "device", "shard_begin", "shard_end", "scan_workgroups", "flags", "resident_workgroups")]
 
 
 class Candidate(C.Structure):
@@ -47,7 +47,21 @@ class EngineStats(C.Structure):
                 ("host_launch_ns", C.c_double), ("scan_workgroups", C.c_int32), ("scan_threads", C.c_int32),
                 ("bytes_per_scan", C.c_int64), ("resident", C.c_int64), ("resident_launches", C.c_int64),
                 ("resident_requests", C.c_int64), ("resident_scan_ns", C.c_double), ("resident_kernel_ns", C.c_double), ("candidates", C.c_int64),
-                ("host_decided", C.c_int64)]
+                ("host_decided", C.c_int64), ("arcs_checked", C.c_int64), ("initial_block_size", C.c_int32), ("current_block_size", C.c_int32),
+                ("comm_ranks", C.c_int32), ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+OPT_NONE, OPT_ADAPTIVE_BLOCK_SIZE, OPT_SMALL_BLOCKS_FOR_DENSE, OPT_REDUCED_COST_CACHING = 0, 1, 2, 4
+
+
+class BlockConfig(C.Structure):
+    """mcf_block_config: the OptimizationConfig fields the plain BlockSearchPivot reads (OptimizationTypes.cs:24-38)."""
+    _fields_ = [("flags", C.c_int32), ("min_block_size", C.c_int32), ("max_block_size", C.c_int32), ("consecutive_hits_before_adapt", C.c_int32),
+                ("min_block_size_ratio", C.c_double), ("block_size_growth_factor", C.c_double), ("block_size_shrink_factor", C.c_double),
+                ("low_hit_rate_threshold", C.c_double), ("high_hit_rate_threshold", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -58,10 +72,13 @@ class NsMetrics(C.Structure):
                 ("tree_update_us", C.c_double), ("potential_update_us", C.c_double), ("setup_us", C.c_double),
                 ("loop_us", C.c_double), ("search_arc_num", C.c_int32),
                 ("block_size", C.c_int32), ("int_width", C.c_int32), ("reserved", C.c_int32),
-                ("degenerate_pivots", C.c_int64), ("potential_nodes", C.c_int64), ("engine", EngineStats)]
+                ("degenerate_pivots", C.c_int64), ("potential_nodes", C.c_int64), ("engine", EngineStats),
+                ("initial_block_size", C.c_int32), ("final_block_size", C.c_int32), ("total_arcs_checked", C.c_int64),
+                ("average_arcs_checked_per_pivot", C.c_double), ("baseline_iterations", C.c_int32), ("config_flags", C.c_int32),
+                ("iteration_ratio", C.c_double), ("reference_selects_cached_pivot", C.c_int32), ("reserved2", C.c_int32)]
 
     def as_dict(self):
-        d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("engine", "reserved")}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("engine", "reserved", "reserved2")}
         d["engine"] = self.engine.as_dict()
         return d
 
@@ -109,6 +126,10 @@ SIGNATURES = {
     "mcf_engine_search_begin": (C.c_int, [C.c_void_p]),
     "mcf_engine_search_end": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
     "mcf_engine_find_entering_local": (C.c_int, [C.c_void_p, _P(Candidate)]),
+    "mcf_engine_search_end_local": (C.c_int, [C.c_void_p, _P(Candidate)]),
+    "mcf_exchange_open": (C.c_int, [_P(C.c_void_p), C.c_char_p, C.c_int32, C.c_int32]),
+    "mcf_exchange_close": (None, [C.c_void_p]),
+    "mcf_exchange_all_gather": (C.c_int, [C.c_void_p, _P(Candidate), _P(Candidate)]),
     "mcf_engine_resolve": (C.c_int, [C.c_void_p, C.c_int32, _P(Candidate), _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
     "mcf_resolve_candidates": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), C.c_int32, _P(Candidate),
                                         _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
@@ -117,6 +138,11 @@ SIGNATURES = {
     "mcf_engine_get_next_arc": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "mcf_engine_set_next_arc": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_engine_get_block_size": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "mcf_block_config_default": (None, [_P(BlockConfig)]),
+    "mcf_block_config_auto": (C.c_int, [_P(BlockConfig), C.c_int32, C.c_int32, _i32p, _i32p]),
+    "mcf_block_initial_size": (C.c_int, [_P(BlockConfig), C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
+    "mcf_block_adapt": (C.c_int, [_P(BlockConfig), C.c_int32, C.c_int64, _P(C.c_int32), _P(C.c_int32)]),
+    "mcf_engine_set_block_config": (C.c_int, [C.c_void_p, _P(BlockConfig), C.c_int32]),
     "mcf_engine_download_pi": (C.c_int, [C.c_void_p, _i64p]),
     "mcf_engine_download_state": (C.c_int, [C.c_void_p, _i8p]),
     "mcf_engine_get_stats": (C.c_int, [C.c_void_p, _P(EngineStats)]),
@@ -134,8 +160,13 @@ SIGNATURES = {
     "mcf_ns_set_supply_type": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_ns_set_pivot_rule": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_ns_enable_optimized_pivot": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mcf_ns_set_optimization_config": (C.c_int, [C.c_void_p, _P(BlockConfig)]),
+    "mcf_ns_enable_optimizations": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mcf_ns_set_auto_configuration": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_ns_set_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "mcf_ns_set_sharding": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32]),
+    "mcf_ns_set_sharding_host": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]),
+    "mcf_ns_set_shard_group": (C.c_int, [C.c_void_p, C.c_int32, _i32p]),
     "mcf_ns_prepare": (C.c_int, [C.c_void_p]),
     "mcf_ns_solve": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "mcf_ns_status": (C.c_int, [C.c_void_p, _P(C.c_int32)]),

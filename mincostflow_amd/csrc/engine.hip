@@ -24,6 +24,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -45,6 +46,7 @@ typedef int (*nccl_comm_init_rank_t)(void **, int, Id128, int);
 typedef int (*nccl_all_gather_t)(const void *, void *, size_t, int, void *, hipStream_t);
 typedef int (*nccl_comm_destroy_t)(void *);
 typedef const char *(*nccl_get_error_string_t)(int);
+typedef int (*nccl_comm_count_t)(void *, int *);
 struct RcclApi {
     void *lib = nullptr;
     nccl_get_unique_id_t get_unique_id = nullptr;
@@ -52,13 +54,13 @@ struct RcclApi {
     nccl_all_gather_t all_gather = nullptr;
     nccl_comm_destroy_t comm_destroy = nullptr;
     nccl_get_error_string_t error_string = nullptr;
+    nccl_comm_count_t comm_count = nullptr;
 };
 RcclApi *rccl()
 {
     static RcclApi api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] {
         api.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!api.lib) api.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (api.lib) {
@@ -67,11 +69,13 @@ RcclApi *rccl()
             api.all_gather = (nccl_all_gather_t)dlsym(api.lib, "ncclAllGather");
             api.comm_destroy = (nccl_comm_destroy_t)dlsym(api.lib, "ncclCommDestroy");
             api.error_string = (nccl_get_error_string_t)dlsym(api.lib, "ncclGetErrorString");
+            api.comm_count = (nccl_comm_count_t)dlsym(api.lib, "ncclCommCount");
         }
-    }
+    });
     return (api.lib && api.get_unique_id && api.comm_init_rank && api.all_gather) ? &api : nullptr;
 }
 constexpr int kNcclChar = 0;   // ncclInt8 / ncclChar
+constexpr int kStageStates = 4096;   // state patches one staged update carries
 
 }  // namespace
 
@@ -82,6 +86,10 @@ struct mcf_engine {
     int begin = 0, end = 0;        // shard [begin, end) of the search arcs
     int count_padded = 0;
     int next_arc = 0, block_size = 0;
+    // plain Block Search sizing (NS.cs:1304-1337) and its adaptive rule (NS.cs:1400-1438); inert unless mcf_engine_set_block_config was called
+    mcf_block_config cfg{};
+    bool cfg_set = false;
+    int dyn_min_block = 0, low_hits = 0, high_hits = 0;
     hipStream_t stream = nullptr;
     int32_t *d_src = nullptr, *d_tgt = nullptr;
     void *d_cost = nullptr, *d_pi = nullptr;
@@ -301,24 +309,28 @@ int flush_pending(mcf_engine *e)
         cand_reset_dirty(e);
         e->cand_valid = false;
     }
-    const int n_pi = (int)e->pend_node.size(), n_st = (int)e->pend_arc.size();
-    if (n_pi == 0 && n_st == 0) return MCF_OK;
-    mcf_engine::Staging &s = e->stage[e->stage_next];
-    e->stage_next ^= 1;
-    if (s.busy) { HIP_TRY(hipEventSynchronize(s.done)); s.busy = false; }
-    if (n_pi) { memcpy(s.nodes, e->pend_node.data(), sizeof(int32_t) * n_pi); memcpy(s.values, e->pend_val.data(), sizeof(int64_t) * n_pi); }
-    if (n_st) { memcpy(s.arcs, e->pend_arc.data(), sizeof(int32_t) * n_st); memcpy(s.states, e->pend_state.data(), sizeof(int32_t) * n_st); }
-    const int blocks = (std::max(n_pi, n_st) + kThreads - 1) / kThreads;
-    if (e->d.int_width == 32)
-        hipLaunchKernelGGL(update_kernel<int32_t>, dim3(blocks), dim3(kThreads), 0, e->stream, (int32_t *)e->d_pi, (const int32_t *)s.d_nodes,
-                           (const int64_t *)s.d_values, n_pi, e->d_state, (const int32_t *)s.d_arcs, (const int32_t *)s.d_states, n_st, e->begin, e->count_padded);
-    else
-        hipLaunchKernelGGL(update_kernel<int64_t>, dim3(blocks), dim3(kThreads), 0, e->stream, (int64_t *)e->d_pi, (const int32_t *)s.d_nodes,
-                           (const int64_t *)s.d_values, n_pi, e->d_state, (const int32_t *)s.d_arcs, (const int32_t *)s.d_states, n_st, e->begin, e->count_padded);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s.done, e->stream));
-    s.busy = true;
-    e->st.update_launches += 1;
+    const int n_pi_all = (int)e->pend_node.size(), n_st_all = (int)e->pend_arc.size();
+    if (n_pi_all == 0 && n_st_all == 0) return MCF_OK;
+    // the staging buffers hold kStageStates state patches: longer lists go out in rounds (the potentials ride in the first)
+    for (int st0 = 0, round = 0; round == 0 || st0 < n_st_all; st0 += kStageStates, ++round) {
+        const int n_pi = round == 0 ? n_pi_all : 0, n_st = std::min(kStageStates, n_st_all - st0);
+        mcf_engine::Staging &s = e->stage[e->stage_next];
+        e->stage_next ^= 1;
+        if (s.busy) { HIP_TRY(hipEventSynchronize(s.done)); s.busy = false; }
+        if (n_pi) { memcpy(s.nodes, e->pend_node.data(), sizeof(int32_t) * n_pi); memcpy(s.values, e->pend_val.data(), sizeof(int64_t) * n_pi); }
+        if (n_st) { memcpy(s.arcs, e->pend_arc.data() + st0, sizeof(int32_t) * n_st); memcpy(s.states, e->pend_state.data() + st0, sizeof(int32_t) * n_st); }
+        const int blocks = (std::max(n_pi, n_st) + kThreads - 1) / kThreads;
+        if (e->d.int_width == 32)
+            hipLaunchKernelGGL(update_kernel<int32_t>, dim3(blocks), dim3(kThreads), 0, e->stream, (int32_t *)e->d_pi, (const int32_t *)s.d_nodes,
+                               (const int64_t *)s.d_values, n_pi, e->d_state, (const int32_t *)s.d_arcs, (const int32_t *)s.d_states, n_st, e->begin, e->count_padded);
+        else
+            hipLaunchKernelGGL(update_kernel<int64_t>, dim3(blocks), dim3(kThreads), 0, e->stream, (int64_t *)e->d_pi, (const int32_t *)s.d_nodes,
+                               (const int64_t *)s.d_values, n_pi, e->d_state, (const int32_t *)s.d_arcs, (const int32_t *)s.d_states, n_st, e->begin, e->count_padded);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(s.done, e->stream));
+        s.busy = true;
+        e->st.update_launches += 1;
+    }
     e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
     return MCF_OK;
 }
@@ -414,7 +426,7 @@ int launch_resident(mcf_engine *e, uint32_t start_seq)
     ResidentParams<T> p;
     p.src = e->d_src; p.tgt = e->d_tgt; p.cost = (const T *)e->d_cost; p.state = e->d_state; p.pi = (T *)e->d_pi;
     p.slots = e->d_slots; p.orig = e->bucket_nodes > 0 ? e->d_orig : nullptr; p.mailbox = e->mailbox; p.exit_word = e->d_exit;
-    p.base = e->begin; p.count_padded = e->count_padded; p.m_s = e->d.search_arc_num; p.block_size = e->block_size;
+    p.base = e->begin; p.count_padded = e->count_padded; p.m_s = e->d.search_arc_num;
     p.start_seq = start_seq; p.idle_ticks = kResidentIdleTicks; p.n_nodes = e->d.node_count; p.max_pi = e->patch_capacity; p.max_st = e->mailbox_max_st; p.poll_replicas = e->poll_replicas; p.poll_sleep = e->poll_sleep;
     const bool opt = e->d.semantics == MCF_SEM_OPTIMIZED;
     switch (e->d.rule) {
@@ -489,6 +501,7 @@ void resident_post(mcf_engine *e, uint32_t seq, uint32_t cmd, bool with_patches)
         if (len1 % e->block_size != 0) rstar = len1 / e->block_size;
     }
     line[3] = (uint32_t)rstar;
+    line[13] = (uint32_t)e->block_size;      // per request: the adaptive rule of the plain Block Search changes it between searches
     line[4] = (uint32_t)n_pi;
     line[5] = (uint32_t)n_st;
     for (int k = 0; k < n_st && k < 2; ++k) { line[6 + 2 * k] = (uint32_t)e->pend_arc[k]; line[7 + 2 * k] = (uint32_t)e->pend_state[k]; }
@@ -557,6 +570,16 @@ void resident_stream(mcf_engine *e)
 
 int search_end(mcf_engine *e, Key *k);
 
+// statistics of a resident launch that has ended (the grid wrote them into the exit record before it left)
+void resident_harvest(mcf_engine *e)
+{
+    const volatile uint32_t *x = e->h_exit;
+    e->st.resident_requests += x[1];
+    e->st.resident_scan_ns += 10.0 * (double)(((uint64_t)x[3] << 32) | x[2]);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->res_start, e->res_stop) == hipSuccess) e->st.resident_kernel_ns += (double)ms * 1e6;
+}
+
 int resident_stop(mcf_engine *e)
 {
     if (!e->resident_running) return MCF_OK;
@@ -575,12 +598,18 @@ int resident_stop(mcf_engine *e)
     HIP_TRY(hipStreamSynchronize(e->stream));       // bounded: the grid leaves on quit, or by itself after kResidentIdleTicks
     e->resident_running = false;
     e->stream_lines = 0;
-    const volatile uint32_t *x = e->h_exit;
-    e->st.resident_requests += x[1];
-    e->st.resident_scan_ns += 10.0 * (double)(((uint64_t)x[3] << 32) | x[2]);
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e->res_start, e->res_stop) == hipSuccess) e->st.resident_kernel_ns += (double)ms * 1e6;
+    resident_harvest(e);
     return MCF_OK;
+}
+
+// the resident grid left on its idle timeout while a request was on its way: count what that launch served, start the grid again; it
+// finds the request in the mailbox (start_seq = the previous request)
+int resident_restart(mcf_engine *e)
+{
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->resident_running = false;
+    resident_harvest(e);
+    return resident_start(e, e->prev_seq);
 }
 
 // wait for the `grid` records of dispatch `seq`, merge them with the rule's ordering
@@ -606,11 +635,7 @@ int collect(mcf_engine *e, int grid, Key *out)
                  slots[(size_t)g * stride].p == slots[(size_t)g * stride + 1].p)) {
             _mm_pause();
             if (e->resident_running && (spins & 0xFFF) == 0xFFF && ((const volatile uint32_t *)e->h_exit)[0] != 0) {
-                // the resident grid left on its idle timeout while this request was on its way: start it again, it will
-                // find the request in the mailbox (start_seq = the previous request)
-                HIP_TRY(hipStreamSynchronize(e->stream));
-                e->resident_running = false;
-                int rc = resident_start(e, e->prev_seq);
+                int rc = resident_restart(e);
                 if (rc) return rc;
             }
             if ((++spins & 0xFFFFF) == 0) {
@@ -771,9 +796,7 @@ int cand_collect(mcf_engine *e, Key *out)
             if (all) break;
             _mm_pause();
             if (e->resident_running && (spins & 0xFFF) == 0xFFF && ((const volatile uint32_t *)e->h_exit)[0] != 0) {
-                HIP_TRY(hipStreamSynchronize(e->stream));
-                e->resident_running = false;
-                int rc = resident_start(e, e->prev_seq);
+                int rc = resident_restart(e);
                 if (rc) return rc;
             }
             if ((++spins & 0xFFFFF) == 0) {
@@ -933,8 +956,11 @@ int local_search(mcf_engine *e, Key *k)
 }
 
 // entering arc, reduced cost and the rule's next_arc from the winning key (host part of the rules)
-void resolve_key_raw(int rule, int semantics, int m_s, int B, int &next_arc, const Key &k, int32_t *found, int32_t *arc, int64_t *rcost)
+// *checked (optional) = arcs the reference's plain BlockSearchPivot examines in this call (its arcsChecked, NS.cs:1345-1372); 0 for the others
+void resolve_key_raw(int rule, int semantics, int m_s, int B, int &next_arc, const Key &k, int32_t *found, int32_t *arc, int64_t *rcost, int64_t *checked = nullptr)
 {
+    const bool counts = rule == MCF_RULE_BLOCK_SEARCH && semantics != MCF_SEM_OPTIMIZED;
+    if (checked) *checked = counts ? m_s : 0;         // nothing eligible, or the cycle ran out before a block boundary: every arc once
     if (k.p == kNone) { *found = 0; *arc = -1; if (rcost) *rcost = 0; return; }
     *found = 1;
     if (rcost) *rcost = k.c;
@@ -946,7 +972,7 @@ void resolve_key_raw(int rule, int semantics, int m_s, int B, int &next_arc, con
     const int64_t r = k.p / B, boundary = (r + 1) * (int64_t)B - 1;   // scan position of the block's last arc
     if (semantics != MCF_SEM_OPTIMIZED) {
         // NS.cs:1358-1397: stop at the boundary -> next_arc = that arc; cycle exhausted first -> unchanged
-        if (boundary <= m_s - 1) next_arc = (int)((boundary + na) % m_s);
+        if (boundary <= m_s - 1) { next_arc = (int)((boundary + na) % m_s); if (checked) *checked = boundary + 1; }
         return;
     }
     // BSPO.cs:49-63,98-103: first range [next_arc, m_s), wrapped range [0, next_arc) only if nothing was found
@@ -961,7 +987,15 @@ void resolve_key_raw(int rule, int semantics, int m_s, int B, int &next_arc, con
 
 void resolve_key(mcf_engine *e, const Key &k, int32_t *found, int32_t *arc, int64_t *rcost)
 {
-    resolve_key_raw(e->d.rule, e->d.semantics, e->d.search_arc_num, e->block_size, e->next_arc, k, found, arc, rcost);
+    int64_t checked = 0;
+    resolve_key_raw(e->d.rule, e->d.semantics, e->d.search_arc_num, e->block_size, e->next_arc, k, found, arc, rcost, &checked);
+    e->st.arcs_checked += checked;
+    if (!*found || !e->cfg_set || !(e->cfg.flags & MCF_OPT_ADAPTIVE_BLOCK_SIZE) || e->d.rule != MCF_RULE_BLOCK_SEARCH || e->d.semantics == MCF_SEM_OPTIMIZED) return;
+    int32_t counters[2] = {e->low_hits, e->high_hits};
+    mcf_block_adapt(&e->cfg, e->dyn_min_block, checked, &e->block_size, counters);      // NS.cs:1400-1438
+    e->low_hits = counters[0];
+    e->high_hits = counters[1];
+    if (e->block_size < 1) e->block_size = 1;       // a block of 0 arcs never reaches a boundary in the reference; keep the kernels' divisor sane
 }
 
 // MINLOC over the shards' candidates with the rule's ordering
@@ -1041,7 +1075,10 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         const int64_t groups4 = ((int64_t)count + kArcsPerThread - 1) / kArcsPerThread;            // threads needed
         // at least four waves per workgroup before a second workgroup is opened: every workgroup is a poller and a record to collect
         // (config 2: 157 x 64 threads -> 40 x 256 took 1.3-1.8 us off each pivot)
-        int g = (int)std::min<int64_t>(kResidentMaxGrid, std::max<int64_t>(1, (groups4 + 255) / 256));
+        // several engines that share a device (arc shards rehearsed on one GPU) must all be co-resident, or a grid that never gets its
+        // CUs would never answer: desc.resident_workgroups caps the grid
+        const int max_grid = desc->resident_workgroups > 0 ? std::min(desc->resident_workgroups, kResidentMaxGrid) : kResidentMaxGrid;
+        int g = (int)std::min<int64_t>(max_grid, std::max<int64_t>(1, (groups4 + 255) / 256));
         int64_t t = ((groups4 + g - 1) / g + 63) / 64 * 64;
         t = std::max<int64_t>(64, std::min<int64_t>(t, kResidentThreads));
         e->res_grid = g;
@@ -1090,8 +1127,8 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         s.cap_nodes = 2 * desc->node_count + 256;
         chk(hipHostMalloc((void **)&s.nodes, sizeof(int32_t) * s.cap_nodes, hipHostMallocMapped | hipHostMallocCoherent));
         chk(hipHostMalloc((void **)&s.values, sizeof(int64_t) * s.cap_nodes, hipHostMallocMapped | hipHostMallocCoherent));
-        chk(hipHostMalloc((void **)&s.arcs, sizeof(int32_t) * 4096, hipHostMallocMapped | hipHostMallocCoherent));
-        chk(hipHostMalloc((void **)&s.states, sizeof(int32_t) * 4096, hipHostMallocMapped | hipHostMallocCoherent));
+        chk(hipHostMalloc((void **)&s.arcs, sizeof(int32_t) * kStageStates, hipHostMallocMapped | hipHostMallocCoherent));
+        chk(hipHostMalloc((void **)&s.states, sizeof(int32_t) * kStageStates, hipHostMallocMapped | hipHostMallocCoherent));
         if (err == hipSuccess) {
             chk(hipHostGetDevicePointer(&s.d_nodes, s.nodes, 0));
             chk(hipHostGetDevicePointer(&s.d_values, s.values, 0));
@@ -1106,7 +1143,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         mcf_engine_destroy(e);
         return rc;
     }
-    // resident mode: wanted by flag or MCF_HIP_RESIDENT=1, never for sharded engines (the RCCL exchange needs the stream)
+    // resident mode: the default (MCF_ENGINE_DISPATCH / MCF_HIP_RESIDENT=0 ask for one dispatch per search)
     {
         const char *env = getenv("MCF_HIP_RESIDENT");
         bool want = (desc->flags & MCF_ENGINE_DISPATCH) == 0;      // resident unless dispatch mode is asked for
@@ -1115,8 +1152,10 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         if (!e->resident_reg && !e->lds_pi) want = false;
         if (env && env[0] == '1') want = true;
         if (env && env[0] == '0') want = false;
+        // an arc shard is served by a resident grid like a whole instance (every workgroup applies every potential patch, state patches
+        // outside the shard are ignored); only the RCCL exchange needs the stream, and mcf_engine_comm_init switches to dispatch mode
         const bool whole = e->begin == 0 && e->end == desc->search_arc_num;
-        if (want && whole && !(desc->flags & (MCF_ENGINE_TIME_EVERY_KERNEL | MCF_ENGINE_NO_INLINE_UPDATE))) {
+        if (want && !(desc->flags & (MCF_ENGINE_TIME_EVERY_KERNEL | MCF_ENGINE_NO_INLINE_UPDATE))) {
             e->mailbox_max_st = 4096;
             e->mailbox_lines = 2 + (e->patch_capacity + e->mailbox_max_st + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
             if (const char *u = getenv("MCF_HIP_POLL_REPLICAS")) { const int v = atoi(u); if (v >= 1 && v <= kMaxReplicas) e->poll_replicas = v; }
@@ -1129,7 +1168,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
                 for (size_t l = 0; l < (size_t)kMailboxTail / 16 + e->mailbox_lines; ++l) mailbox_write_line(e->mailbox + 16 * l, zero);
                 _mm_sfence();
                 e->resident_ok = true;
-                e->cand_on = (desc->flags & MCF_ENGINE_CANDIDATES) && e->resident_reg && desc->rule == MCF_RULE_BEST_ELIGIBLE &&
+                e->cand_on = (desc->flags & MCF_ENGINE_CANDIDATES) && whole && e->resident_reg && desc->rule == MCF_RULE_BEST_ELIGIBLE &&
                              2 * (int64_t)desc->search_arc_num <= (int64_t)kCandMaxAvgDegree * desc->node_count;
             }
         }
@@ -1148,6 +1187,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
     e->st.resident = e->resident_ok ? 1 : 0;
     e->st.candidates = e->cand_on ? 1 : 0;
     e->st.bytes_per_scan = (int64_t)(desc->int_width == 64 ? 17 : 13) * count + (int64_t)w * desc->node_count;
+    e->st.initial_block_size = e->st.current_block_size = e->block_size;
     *out = e;
     return MCF_OK;
 }
@@ -1284,7 +1324,10 @@ int mcf_engine_patch_state(mcf_engine *e, int32_t count, const int32_t *arcs, co
         for (size_t j = 0; j < e->pend_arc.size(); ++j)
             if (e->pend_arc[j] == where) { e->pend_state[j] = states[i]; dup = true; }
         if (dup) continue;
-        if ((int)e->pend_arc.size() >= 64) { int rc = flush_pending(e); if (rc) return rc; }
+        // Dispatch mode ships long lists with update_kernel, in stream order before the next scan.  A resident grid would only run that
+        // kernel after it has left (and would have scanned with stale state meanwhile): there the list simply grows -- the mailbox
+        // carries up to mailbox_max_st state patches and search_begin stops the grid first for anything longer.
+        if (!e->resident_ok && (int)e->pend_arc.size() >= 64) { int rc = flush_pending(e); if (rc) return rc; }
         e->pend_arc.push_back(where);
         e->pend_state.push_back(states[i]);
     }
@@ -1429,17 +1472,38 @@ int mcf_engine_find_entering(mcf_engine *e, int32_t *found, int32_t *arc, int64_
 int mcf_engine_search_begin(mcf_engine *e)
 {
     if (!e) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_search_begin: null argument");
-    if (e->begin != 0 || e->end != e->d.search_arc_num) return mcf::fail(MCF_ERR_STATE, "sharded engine: use mcf_engine_find_entering_local / _sharded");
     return search_begin(e);
 }
 
 int mcf_engine_search_end(mcf_engine *e, int32_t *found, int32_t *arc, int64_t *reduced_cost)
 {
     if (!e || !found || !arc) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_search_end: null argument");
+    if (e->begin != 0 || e->end != e->d.search_arc_num) return mcf::fail(MCF_ERR_STATE, "sharded engine: use mcf_engine_search_end_local + mcf_engine_resolve");
     Key k;
     const int rc = search_end(e, &k);
     if (rc) return rc;
     resolve_key(e, k, found, arc, reduced_cost);
+    return MCF_OK;
+}
+
+namespace {
+void key_to_candidate(const mcf_engine *e, const Key &k, mcf_candidate *out)
+{
+    out->reduced_cost = k.p == kNone ? 0 : k.c;
+    out->pos = k.p;
+    if (k.p == kNone) out->arc = -1;
+    else if (e->d.rule == MCF_RULE_BEST_ELIGIBLE) out->arc = (int32_t)k.p;
+    else { const int na = e->next_arc >= e->d.search_arc_num ? 0 : e->next_arc; out->arc = (int32_t)(((int64_t)k.p + na) % e->d.search_arc_num); }
+}
+}  // namespace
+
+int mcf_engine_search_end_local(mcf_engine *e, mcf_candidate *out)
+{
+    if (!e || !out) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_search_end_local: null argument");
+    Key k;
+    const int rc = search_end(e, &k);
+    if (rc) return rc;
+    key_to_candidate(e, k, out);
     return MCF_OK;
 }
 
@@ -1449,11 +1513,7 @@ int mcf_engine_find_entering_local(mcf_engine *e, mcf_candidate *out)
     Key k;
     int rc = local_search(e, &k);
     if (rc) return rc;
-    out->reduced_cost = k.p == kNone ? 0 : k.c;
-    out->pos = k.p;
-    if (k.p == kNone) out->arc = -1;
-    else if (e->d.rule == MCF_RULE_BEST_ELIGIBLE) out->arc = (int32_t)k.p;
-    else { const int na = e->next_arc >= e->d.search_arc_num ? 0 : e->next_arc; out->arc = (int32_t)(((int64_t)k.p + na) % e->d.search_arc_num); }
+    key_to_candidate(e, k, out);
     return MCF_OK;
 }
 
@@ -1494,6 +1554,24 @@ int mcf_engine_set_next_arc(mcf_engine *e, int32_t next_arc)
     return MCF_OK;
 }
 int mcf_engine_get_block_size(mcf_engine *e, int32_t *b) { if (!e || !b) return mcf::fail(MCF_ERR_INVALID, "null argument"); *b = e->block_size; return MCF_OK; }
+
+int mcf_engine_set_block_config(mcf_engine *e, const mcf_block_config *c, int32_t graph_node_count)
+{
+    if (!e || !c || graph_node_count < 0) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_set_block_config: bad arguments");
+    if (e->st.searches > 0 || e->in_flight != mcf_engine::kNoSearch) return mcf::fail(MCF_ERR_STATE, "mcf_engine_set_block_config: call before the first search");
+    if (c->consecutive_hits_before_adapt < 0 || c->min_block_size < 0) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_set_block_config: negative sizes");
+    e->cfg = *c;
+    e->cfg_set = true;
+    e->low_hits = e->high_hits = 0;
+    if (e->d.rule != MCF_RULE_BLOCK_SEARCH || e->d.semantics == MCF_SEM_OPTIMIZED) return MCF_OK;   // BSPO.cs:27-28 ignores the configuration
+    int32_t b = 0, dyn_min = 0;
+    const int rc = mcf_block_initial_size(c, e->d.search_arc_num, graph_node_count, &b, &dyn_min);      // NS.cs:1304-1336
+    if (rc) return rc;
+    e->dyn_min_block = dyn_min;
+    if (e->d.block_size <= 0) e->block_size = std::max(1, b);
+    e->st.initial_block_size = e->st.current_block_size = e->block_size;
+    return MCF_OK;
+}
 
 int mcf_engine_download_pi(mcf_engine *e, int64_t *out)
 {
@@ -1542,6 +1620,7 @@ int mcf_engine_get_stats(mcf_engine *e, mcf_engine_stats *out)
     const double ns_per_tick = (mcf::now_ns() - e->cal_ns) / std::max(1.0, (double)__rdtsc() - e->cal_ticks);
     e->st.host_wait_ns = e->wait_ticks * ns_per_tick;
     e->st.host_launch_ns = e->launch_ticks * ns_per_tick;
+    e->st.current_block_size = e->block_size;
     *out = e->st;
     return MCF_OK;
 }
@@ -1559,6 +1638,9 @@ int mcf_engine_reset_stats(mcf_engine *e)
     e->st.bytes_per_scan = keep.bytes_per_scan;
     e->st.resident = keep.resident;
     e->st.candidates = keep.candidates;
+    e->st.initial_block_size = keep.initial_block_size;
+    e->st.current_block_size = e->block_size;
+    e->st.comm_ranks = keep.comm_ranks;
     return MCF_OK;
 }
 
@@ -1625,12 +1707,23 @@ int mcf_engine_comm_init(mcf_engine *e, const uint8_t id[128], int32_t rank, int
     RcclApi *r = rccl();
     if (!r) return mcf::fail(MCF_ERR_COMM, "librccl.so could not be loaded");
     HIP_TRY(hipSetDevice(e->d.device));
+    // the all-gather runs on the engine's stream between the scans: one dispatch per search from here on
+    if (int rcs = resident_stop(e)) return rcs;
+    if (e->resident_ok) {
+        if (e->in_flight != mcf_engine::kNoSearch) return mcf::fail(MCF_ERR_STATE, "mcf_engine_comm_init: a search is in flight");
+        e->resident_ok = false;
+        e->st.resident = 0;
+        e->st.scan_workgroups = e->grid;
+        e->st.scan_threads = e->lds_pi ? kResidentThreads : kThreads;
+    }
     Id128 nid;
     memcpy(nid.b, id, 128);
     const int rc = r->comm_init_rank(&e->comm, world, nid, rank);
     if (rc != 0) return mcf::fail(MCF_ERR_COMM, "ncclCommInitRank: %s", r->error_string ? r->error_string(rc) : "error");
     e->rank = rank;
     e->world = world;
+    e->st.comm_ranks = world;
+    if (r->comm_count) { int seen = 0; if (r->comm_count(e->comm, &seen) == 0) e->st.comm_ranks = seen; }     // as the communicator itself reports it
     HIP_TRY(hipMalloc((void **)&e->d_cand_local, sizeof(mcf_candidate)));
     HIP_TRY(hipMalloc((void **)&e->d_cand_all, sizeof(mcf_candidate) * world));
     HIP_TRY(hipHostMalloc((void **)&e->h_cand_all, sizeof(mcf_candidate) * world, hipHostMallocDefault));

@@ -384,7 +384,7 @@ struct ResidentParams {
     const int32_t *orig;        // bucketed layout (see ScanParams), only read by the PERM variant
     const uint32_t *mailbox;    // fine-grained VRAM, written by the host through the BAR
     uint32_t *exit_word;        // pinned host memory: [0] exit code, [1] requests served, [2..3] scan ticks of workgroup 0
-    int32_t base, count_padded, m_s, block_size;
+    int32_t base, count_padded, m_s;
     uint32_t start_seq, idle_ticks;
     int32_t n_nodes;            // length of pi
     int32_t max_pi;             // potential patches the mailbox can hold
@@ -524,7 +524,8 @@ __device__ __forceinline__ void publish_candidates(int64_t c1, uint32_t p1, int6
 
 // Mailbox: lines of 64 bytes; dword 15 of EVERY line repeats seq, so a torn read of any line is detected and retried.
 //   line 0      [0] seq [1] cmd (0 scan, 1 quit, 2 apply) [2] next_arc [3] rstar [4] n_pi [5] n_st [6..9] state patches 0,1 {arc, value}
-//               [10..12] potential patch 0 {node, lo, hi} [13] apply: entry lines valid so far [14] apply: post counter
+//               [10..12] potential patch 0 {node, lo, hi} [13] scan: block size of THIS search (Block Search; the reference's adaptive
+//               rule changes it between searches, NS.cs:1400-1438) / apply: entry lines valid so far [14] apply: post counter
 // cmd 2 ("apply") streams a long potential list while the host is still walking the subtree: the entry lines 1..[13] of the NEXT scan
 // request are in place, every workgroup applies those it has not applied yet and goes back to polling (no answer).  The posts are
 // cumulative, so one that is overwritten before a workgroup saw it loses nothing; the scan request finishes the list.
@@ -608,6 +609,7 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
         const bool timed_out = s_timeout == 2u;
         const bool line1_staged = lm[31] == seq;           // line 1 came along with the poll and is complete
         const int next_arc = (int)lm[2], rstar = (int)lm[3];
+        const int block_size = (int)lm[13] > 0 ? (int)lm[13] : 1;      // scan requests only (an apply post keeps its line count there)
         const int st_arc0 = (int)lm[6], st_arc1 = (int)lm[8];
         const uint32_t st_val0 = lm[7], st_val1 = lm[9];
         const uint32_t p0_node = lm[10], p0_lo = lm[11], p0_hi = lm[12];
@@ -749,14 +751,14 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
             best.r = kNone;
             best.p = kNone;
             if (PIREG) {
-                fold_tile<T, RULE, OPT>(mine, ps, pt, p.base + my_i0, p.m_s, next_arc, p.block_size, rstar, best);
+                fold_tile<T, RULE, OPT>(mine, ps, pt, p.base + my_i0, p.m_s, next_arc, block_size, rstar, best);
             } else if (REG) {
-                eval_tile<T, RULE, OPT>(mine, pi_view, p.base + my_i0, p.m_s, next_arc, p.block_size, rstar, best, sub_node, v0);
+                eval_tile<T, RULE, OPT>(mine, pi_view, p.base + my_i0, p.m_s, next_arc, block_size, rstar, best, sub_node, v0);
             } else {
                 for (int i0 = my_i0; i0 < p.count_padded; i0 += gridDim.x * nt * kArcsPerThread) {
                     TileData<T> d;
                     load_tile<T>(p.src, p.tgt, p.cost, p.state, i0, d);
-                    eval_tile<T, RULE, OPT, PERM>(d, pi_view, p.base + i0, p.m_s, next_arc, p.block_size, rstar, best, -1, (T)0, p.orig, p.base);
+                    eval_tile<T, RULE, OPT, PERM>(d, pi_view, p.base + i0, p.m_s, next_arc, block_size, rstar, best, -1, (T)0, p.orig, p.base);
                 }
                 if (PERM && best.p != kNone) best.p = (uint32_t)p.orig[(int)best.p - p.base];
             }

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include <x86intrin.h>
@@ -31,6 +32,8 @@ struct mcf_ns {
     int supply_type = MCF_SUPPLY_GEQ, rule = MCF_RULE_BLOCK_SEARCH;   // NS.cs:38, :77
     bool optimized_pivot = false;                                      // NS.cs:34
     int device = 0, int_width = 0, block_size = 0, engine_flags = 0;
+    bool auto_config = true;                                           // NS.cs:90
+    mcf_block_config config{};                                         // _optimizationConfig, NS.cs:89
     // arcs: m + 2n entries (NS.cs:130)
     std::vector<int32_t> tail, head;
     std::vector<int64_t> lower, upper, cost, flow, orig_lower;
@@ -61,10 +64,18 @@ struct mcf_ns {
     int engine_rc = 0;                // first error of an engine call made from inside a pivot
     bool hand_over = false;           // a device engine is attached: state writes and potential pieces go to it as they arise
     int64_t sigma = 0;
-    // engine + sharding
+    // engine(s) + sharding.  kRccl / kHost: one process per GPU, this rank's engine holds one arc shard and the candidates are exchanged
+    // by ncclAllGather / through shared memory; kGroup: this process drives every shard itself (peers[] next to engine)
+    enum ShardMode { kWhole = 0, kRccl, kHost, kGroup };
     mcf_engine *engine = nullptr;
-    bool sharded = false;
+    std::vector<mcf_engine *> peers;          // kGroup: shards 1 .. R-1 (shard 0 is `engine`)
+    std::vector<int32_t> group_devices;
+    std::vector<mcf_candidate> cands;
+    int shard_mode = kWhole;
+    bool sharded = false;                     // kRccl
     uint8_t nccl_id[128];
+    std::string exchange_name;
+    mcf_exchange *exchange = nullptr;
     int rank = 0, world = 1;
     // trace / metrics
     int32_t *trace = nullptr;
@@ -74,6 +85,65 @@ struct mcf_ns {
 };
 
 namespace {
+
+// ---- the engine calls of a pivot, fanned out to every shard this process drives
+int engines_patch_state(mcf_ns *s, int32_t count, const int32_t *arcs, const int8_t *states)
+{
+    int rc = mcf_engine_patch_state(s->engine, count, arcs, states);       // every engine keeps the writes that fall into its shard
+    for (size_t i = 0; i < s->peers.size() && !rc; ++i) rc = mcf_engine_patch_state(s->peers[i], count, arcs, states);
+    return rc;
+}
+int engines_append_potential(mcf_ns *s, int32_t count, const int32_t *nodes, const int64_t *values)
+{
+    int rc = mcf_engine_append_potential(s->engine, count, nodes, values); // the potentials are replicated on every shard
+    for (size_t i = 0; i < s->peers.size() && !rc; ++i) rc = mcf_engine_append_potential(s->peers[i], count, nodes, values);
+    return rc;
+}
+int engines_search_begin(mcf_ns *s)
+{
+    if (s->shard_mode == mcf_ns::kRccl) return MCF_OK;                      // one blocking call (the all-gather runs on the engine's stream)
+    int rc = mcf_engine_search_begin(s->engine);
+    for (size_t i = 0; i < s->peers.size() && !rc; ++i) rc = mcf_engine_search_begin(s->peers[i]);
+    return rc;
+}
+int engines_search_end(mcf_ns *s, int32_t *found, int32_t *arc)
+{
+    switch (s->shard_mode) {
+    case mcf_ns::kWhole: return mcf_engine_search_end(s->engine, found, arc, nullptr);
+    case mcf_ns::kRccl: return mcf_engine_find_entering_sharded(s->engine, found, arc, nullptr);
+    case mcf_ns::kHost: {
+        mcf_candidate mine;
+        int rc = mcf_engine_search_end_local(s->engine, &mine);
+        if (!rc) rc = mcf_exchange_all_gather(s->exchange, &mine, s->cands.data());
+        if (!rc) rc = mcf_engine_resolve(s->engine, s->world, s->cands.data(), found, arc, nullptr);
+        return rc;
+    }
+    default: {
+        int rc = mcf_engine_search_end_local(s->engine, &s->cands[0]);
+        for (size_t i = 0; i < s->peers.size() && !rc; ++i) rc = mcf_engine_search_end_local(s->peers[i], &s->cands[i + 1]);
+        // every shard's rule state (next_arc, adaptive block size) advances with the same global answer
+        if (!rc) rc = mcf_engine_resolve(s->engine, (int32_t)s->cands.size(), s->cands.data(), found, arc, nullptr);
+        for (size_t i = 0; i < s->peers.size() && !rc; ++i) {
+            int32_t f2 = 0, a2 = -1;
+            rc = mcf_engine_resolve(s->peers[i], (int32_t)s->cands.size(), s->cands.data(), &f2, &a2, nullptr);
+        }
+        return rc;
+    }
+    }
+}
+void engines_park(mcf_ns *s)
+{
+    if (s->engine) mcf_engine_park(s->engine);
+    for (mcf_engine *e : s->peers) mcf_engine_park(e);
+}
+void engines_destroy(mcf_ns *s)
+{
+    if (s->engine) mcf_engine_destroy(s->engine);
+    for (mcf_engine *e : s->peers) mcf_engine_destroy(e);
+    s->engine = nullptr;
+    s->peers.clear();
+    if (s->exchange) { mcf_exchange_close(s->exchange); s->exchange = nullptr; }
+}
 
 // ---- NS.cs:624-669
 bool bounds_ok(const mcf_ns *s)
@@ -337,7 +407,7 @@ void shift_potentials(mcf_ns *s)
         a = nxt[a];
         if (s->hand_over && i + 1 - s->moved_sent >= kWalkPiece && count - (i + 1) >= kWalkPiece / 2) {
             // the grid applies this piece while the walk goes on (resident mode); the search after the pivot finishes the list
-            if (!s->engine_rc) s->engine_rc = mcf_engine_append_potential(s->engine, i + 1 - s->moved_sent, nodes + s->moved_sent, vals + s->moved_sent);
+            if (!s->engine_rc) s->engine_rc = engines_append_potential(s, i + 1 - s->moved_sent, nodes + s->moved_sent, vals + s->moved_sent);
             s->moved_sent = i + 1;
         }
     }
@@ -358,7 +428,7 @@ bool pivot_front(mcf_ns *s, int arc, double *t_pot)
     if (!change && s->delta == 0) return true;
     decide_states(s, change);
     // the engine hears about the state writes before any piece of the potential list (the pieces may start travelling at once)
-    if (s->hand_over && !s->engine_rc) s->engine_rc = mcf_engine_patch_state(s->engine, s->n_state, s->st_arc, s->st_val);
+    if (s->hand_over && !s->engine_rc) s->engine_rc = engines_patch_state(s, s->n_state, s->st_arc, s->st_val);
     if (s->delta == 0) s->metrics.degenerate_pivots++;
     if (change) {
         const double t1 = ticks();
@@ -438,6 +508,7 @@ int mcf_ns_create(mcf_ns **out, int32_t node_count, int32_t arc_count, const int
             return mcf::fail(MCF_ERR_INVALID, "arc %d: end point out of range", e);
     mcf_ns *s = new mcf_ns();
     s->n = node_count; s->m = arc_count;
+    mcf_block_config_default(&s->config);
     const size_t A = (size_t)arc_count + 2 * (size_t)node_count, N = (size_t)node_count + 1;
     s->tail.assign(A, 0); s->head.assign(A, 0);
     std::copy(source, source + arc_count, s->tail.begin());
@@ -455,7 +526,7 @@ int mcf_ns_create(mcf_ns **out, int32_t node_count, int32_t arc_count, const int
 void mcf_ns_destroy(mcf_ns *s)
 {
     if (!s) return;
-    if (s->engine) mcf_engine_destroy(s->engine);
+    engines_destroy(s);
     delete s;
 }
 
@@ -509,6 +580,26 @@ int mcf_ns_enable_optimized_pivot(mcf_ns *s, int32_t enable)
     s->optimized_pivot = enable != 0;
     return MCF_OK;
 }
+int mcf_ns_set_optimization_config(mcf_ns *s, const mcf_block_config *config)       // NS.cs:557-561
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    if (!config) return mcf::fail(MCF_ERR_INVALID, "config must not be null (ArgumentNullException, NS.cs:559)");
+    s->config = *config;
+    s->auto_config = false;
+    return MCF_OK;
+}
+int mcf_ns_enable_optimizations(mcf_ns *s, int32_t flags)                            // NS.cs:549-552
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    s->config.flags = flags;
+    return MCF_OK;
+}
+int mcf_ns_set_auto_configuration(mcf_ns *s, int32_t enable)                         // NS.cs:567-570
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    s->auto_config = enable != 0;
+    return MCF_OK;
+}
 int mcf_ns_set_device(mcf_ns *s, int32_t device, int32_t int_width, int32_t block_size, int32_t engine_flags)
 {
     if (!s || (int_width != 0 && int_width != 32 && int_width != 64) || block_size < 0 || device < 0) return mcf::fail(MCF_ERR_INVALID, "mcf_ns_set_device: bad arguments");
@@ -519,7 +610,22 @@ int mcf_ns_set_sharding(mcf_ns *s, const uint8_t id[128], int32_t rank, int32_t 
 {
     if (!s || !id || world < 1 || rank < 0 || rank >= world) return mcf::fail(MCF_ERR_INVALID, "mcf_ns_set_sharding: bad arguments");
     memcpy(s->nccl_id, id, 128);
-    s->rank = rank; s->world = world; s->sharded = true;   // world 1 still goes through the RCCL exchange (tests)
+    s->rank = rank; s->world = world; s->sharded = true; s->shard_mode = mcf_ns::kRccl;   // world 1 still goes through the RCCL exchange (tests)
+    return MCF_OK;
+}
+int mcf_ns_set_sharding_host(mcf_ns *s, const char *exchange_name, int32_t rank, int32_t world)
+{
+    if (!s || !exchange_name || exchange_name[0] != '/' || world < 1 || rank < 0 || rank >= world) return mcf::fail(MCF_ERR_INVALID, "mcf_ns_set_sharding_host: bad arguments");
+    s->exchange_name = exchange_name;
+    s->rank = rank; s->world = world; s->shard_mode = mcf_ns::kHost; s->sharded = false;
+    return MCF_OK;
+}
+int mcf_ns_set_shard_group(mcf_ns *s, int32_t shards, const int32_t *devices)
+{
+    if (!s || shards < 1 || shards > 64 || !devices) return mcf::fail(MCF_ERR_INVALID, "mcf_ns_set_shard_group: bad arguments");
+    for (int i = 0; i < shards; ++i) if (devices[i] < 0) return mcf::fail(MCF_ERR_INVALID, "mcf_ns_set_shard_group: negative device");
+    s->group_devices.assign(devices, devices + shards);
+    s->world = shards; s->rank = 0; s->shard_mode = mcf_ns::kGroup; s->sharded = false;
     return MCF_OK;
 }
 int mcf_ns_set_pivot_limit(mcf_ns *s, int64_t max_pivots)
@@ -612,17 +718,45 @@ int mcf_ns_prepare(mcf_ns *s)
     d.block_size = s->block_size;
     d.device = s->device;
     d.flags = s->engine_flags;
-    if (s->sharded) {
-        rc = mcf_shard_range(s->search_arcs, s->rank, s->world, &d.shard_begin, &d.shard_end);
+    // NS.cs:237-250: the solver configures itself from the problem's shape unless told otherwise.  (The reference analyses after
+    // TransformToStandardForm; the analysis only reads the graph, which that step does not touch.)
+    if (s->auto_config) { rc = mcf_block_config_auto(&s->config, s->n, s->m, s->tail.data(), s->head.data()); if (rc) return rc; }
+    engines_destroy(s);
+    const int shards = s->shard_mode == mcf_ns::kGroup ? (int)s->group_devices.size() : 1;
+    for (int r = 0; r < shards; ++r) {
+        mcf_engine_desc dr = d;
+        if (s->shard_mode != mcf_ns::kWhole) {
+            rc = mcf_shard_range(s->search_arcs, s->shard_mode == mcf_ns::kGroup ? r : s->rank, s->world, &dr.shard_begin, &dr.shard_end);
+            if (rc) return rc;
+        }
+        if (s->shard_mode == mcf_ns::kRccl) dr.flags |= MCF_ENGINE_DISPATCH;      // the RCCL exchange runs on the engine's stream between the scans
+        if (s->shard_mode == mcf_ns::kGroup) {
+            dr.device = s->group_devices[r];
+            const int sharing = (int)std::count(s->group_devices.begin(), s->group_devices.end(), dr.device);
+            if (sharing > 1) {                       // shards rehearsed on one GPU: every grid must fit beside the others
+                dr.flags |= MCF_ENGINE_SHARE_DEVICE;
+                dr.resident_workgroups = std::max(1, 256 / sharing);
+            }
+        }
+        mcf_engine *e = nullptr;
+        rc = mcf_engine_create(&e, &dr);
         if (rc) return rc;
-        d.flags |= MCF_ENGINE_DISPATCH;      // the RCCL exchange runs on the engine's stream between the scans
+        if (r == 0) s->engine = e; else s->peers.push_back(e);
+        rc = mcf_engine_upload(e, s->tail.data(), s->head.data(), s->cost.data(), s->state.data(), s->pi.data());
+        if (rc) return rc;
+        if (s->shard_mode == mcf_ns::kRccl) { rc = mcf_engine_comm_init(e, s->nccl_id, s->rank, s->world); if (rc) return rc; }
+        rc = mcf_engine_set_block_config(e, &s->config, s->n);
+        if (rc) return rc;
     }
-    if (s->engine) { mcf_engine_destroy(s->engine); s->engine = nullptr; }
-    rc = mcf_engine_create(&s->engine, &d);
-    if (rc) return rc;
-    rc = mcf_engine_upload(s->engine, s->tail.data(), s->head.data(), s->cost.data(), s->state.data(), s->pi.data());
-    if (rc) return rc;
-    if (s->sharded) { rc = mcf_engine_comm_init(s->engine, s->nccl_id, s->rank, s->world); if (rc) return rc; }
+    s->cands.assign((size_t)std::max(1, s->world), mcf_candidate{0, 0xFFFFFFFFu, -1});
+    if (s->shard_mode == mcf_ns::kHost) { rc = mcf_exchange_open(&s->exchange, s->exchange_name.c_str(), s->rank, s->world); if (rc) return rc; }
+    s->metrics.config_flags = s->config.flags;
+    if (!s->optimized_pivot && (s->config.flags & MCF_OPT_REDUCED_COST_CACHING) && s->rule == MCF_RULE_BLOCK_SEARCH) {
+        // NS.cs:855-883: `_nodeCount * _nodeCount` is an int product (it wraps) before the conversion to double
+        const int32_t nn = (int32_t)((uint32_t)s->n * (uint32_t)s->n);
+        const double density = (double)s->search_arcs / (double)nn;
+        s->metrics.reference_selects_cached_pivot = (density < 0.01 && s->search_arcs < 10000) ? 1 : 0;
+    }
     s->metrics.search_arc_num = s->search_arcs;
     s->metrics.int_width = d.int_width;
     mcf_engine_get_block_size(s->engine, &s->metrics.block_size);
@@ -649,17 +783,15 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     s->hand_over = true;
     s->engine_rc = 0;
     // The search for pivot k+1 is posted as soon as the device has what it depends on (State[] writes, potentials); the rest of pivot k
-    // (flows around the cycle, re-hanging the subtree) runs while the device is searching.  Sharded engines search in one blocking
-    // call (the RCCL exchange), so for them the two halves simply follow each other.
-    const bool split = !s->sharded;
-    if (split) { rc = mcf_engine_search_begin(s->engine); if (rc) return rc; }
-    for (;;) {
+    // (flows around the cycle, re-hanging the subtree) runs while the device is searching.  Engines sharded over RCCL search in one
+    // blocking call (the all-gather runs on their stream), so for them the two halves simply follow each other.
+    rc = engines_search_begin(s);
+    while (!rc) {
         const double t0 = ticks();
         int32_t found = 0, arc = -1;
-        rc = split ? mcf_engine_search_end(s->engine, &found, &arc, nullptr) : mcf_engine_find_entering_sharded(s->engine, &found, &arc, nullptr);
+        rc = engines_search_end(s, &found, &arc);
         t_search += ticks() - t0;
-        if (rc) return rc;
-        if (!found) break;
+        if (rc || !found) break;
         if (s->trace && it < s->trace_cap) s->trace[it] = arc;
         ++it;
         if (it > max_iter) { s->status = MCF_INFEASIBLE; break; }                          // NS.cs:311-317
@@ -668,27 +800,42 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         const double t1 = ticks();
         rc = s->engine_rc;
         if (!rc && s->moved_n > s->moved_sent)
-            rc = mcf_engine_append_potential(s->engine, (int32_t)(s->moved_n - s->moved_sent), s->moved.data() + s->moved_sent, s->moved_val.data() + s->moved_sent);
-        if (!rc && split) rc = mcf_engine_search_begin(s->engine);
+            rc = engines_append_potential(s, (int32_t)(s->moved_n - s->moved_sent), s->moved.data() + s->moved_sent, s->moved_val.data() + s->moved_sent);
+        if (!rc) rc = engines_search_begin(s);
         t_pot += ticks() - t1;
-        if (rc) return rc;
+        if (rc) break;                     // the pivot stays half done: the solver is unusable after an engine error, but nothing is left running
         pivot_back(s, &t_tree);
         s->metrics.potential_nodes += (int64_t)s->moved_n;
     }
+    // ONE way out, error or not: no hand-over pending, no resident grid left spinning, trace length and iteration count filled in
     s->hand_over = false;
-    mcf_engine_park(s->engine);      // a resident scan grid must not outlive Solve()
+    const char *first_error = rc ? mcf_last_error() : nullptr;
+    std::string keep_error = first_error ? first_error : "";
+    engines_park(s);                 // a resident scan grid must not outlive Solve()
     s->trace_len = std::min(it, s->trace_cap);
     s->metrics.iterations = it;
-    if (s->status == MCF_NOT_SOLVED && !limited) finish(s);
+    if (!rc && s->status == MCF_NOT_SOLVED && !limited) finish(s);
     // the phase buckets were counted in time-stamp-counter ticks (a clock call per phase costs 20+ ns, seven of them per pivot): scale them
     const double ns_per_tick = (mcf::now_ns() - t_start) / std::max(1.0, ticks() - tick_start);
     s->metrics.pivot_search_us = t_search * ns_per_tick / 1e3;
     s->metrics.tree_update_us = t_tree * ns_per_tick / 1e3;
     s->metrics.potential_update_us = t_pot * ns_per_tick / 1e3;
     mcf_engine_get_stats(s->engine, &s->metrics.engine);
+    // the rest of SolverMetrics: NS.cs:262-270 (initial block size), :276 (expected iterations), :344-357
+    const bool plain_block = s->rule == MCF_RULE_BLOCK_SEARCH && !s->optimized_pivot;
+    s->metrics.initial_block_size = plain_block ? s->metrics.engine.initial_block_size : 0;
+    s->metrics.final_block_size = plain_block ? s->metrics.engine.current_block_size : 0;
+    s->metrics.total_arcs_checked = s->metrics.engine.arcs_checked;
+    s->metrics.average_arcs_checked_per_pivot = it > 0 ? (double)s->metrics.total_arcs_checked / (double)it : 0;
+    {
+        const double expected = std::sqrt((double)s->search_arcs) * s->n * 0.5;
+        s->metrics.baseline_iterations = expected < 2147483648.0 ? (int32_t)expected : INT32_MIN;     // what (int) of an oversized double gives on x64
+    }
+    s->metrics.iteration_ratio = s->metrics.baseline_iterations > 0 ? (double)it / s->metrics.baseline_iterations : 1.0;
     s->metrics.loop_us = (mcf::now_ns() - t_start) / 1e3;
     s->metrics.total_solve_us = s->metrics.loop_us + s->metrics.setup_us;
     if (status) *status = s->status;
+    if (rc) { mcf::set_error("%s", keep_error.c_str()); return rc; }
     return MCF_OK;
 }
 

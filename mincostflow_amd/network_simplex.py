@@ -160,12 +160,31 @@ class NetworkSimplex:
     def enable_optimized_pivot(self, enable: bool = True):     # NetworkSimplex.cs:532-535
         L.check(L.lib().mcf_ns_enable_optimized_pivot(self._h, int(enable))); return self
 
+    # --- NetworkSimplex.cs:549-570
+    def set_optimization_config(self, config):                 # SetOptimizationConfig: switches auto-configuration off
+        L.check(L.lib().mcf_ns_set_optimization_config(self._h, C.byref(config))); return self
+
+    def enable_optimizations(self, flags: int):
+        L.check(L.lib().mcf_ns_enable_optimizations(self._h, flags)); return self
+
+    def set_auto_configuration(self, enable: bool = True):     # the reference's default is on
+        L.check(L.lib().mcf_ns_set_auto_configuration(self._h, int(enable))); return self
+
     # --- device options (no counterpart in the reference)
     def set_device(self, device=0, int_width=0, block_size=0, engine_flags=0):
         L.check(L.lib().mcf_ns_set_device(self._h, device, int_width, block_size, engine_flags)); return self
 
     def set_sharding(self, nccl_id: np.ndarray, rank: int, world: int):
         L.check(L.lib().mcf_ns_set_sharding(self._h, np.ascontiguousarray(nccl_id, np.uint8), rank, world)); return self
+
+    def set_sharding_host(self, exchange_name: str, rank: int, world: int):
+        """Arc shards over `world` ranks of one node, candidates exchanged through shared memory (mcf_exchange_*)."""
+        L.check(L.lib().mcf_ns_set_sharding_host(self._h, exchange_name.encode(), rank, world)); return self
+
+    def set_shard_group(self, devices):
+        """Arc shards inside this process: one engine per entry of `devices` (entries may repeat), reduced by the host thread."""
+        d = _i32(devices)
+        L.check(L.lib().mcf_ns_set_shard_group(self._h, d.shape[0], d)); return self
 
     def set_pivot_limit(self, max_pivots: int):
         L.check(L.lib().mcf_ns_set_pivot_limit(self._h, max_pivots)); return self
@@ -249,6 +268,25 @@ class NetworkSimplex:
                     nodes=nd, sigma=sigma.value)
 
 
+def block_config(**kw) -> "L.BlockConfig":
+    """new OptimizationConfig { ... } (OptimizationTypes.cs:24-38): the defaults, with the given fields replaced."""
+    c = L.BlockConfig()
+    L.lib().mcf_block_config_default(C.byref(c))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def auto_block_config(node_count: int, source, target) -> "L.BlockConfig":
+    """What the reference's auto-configuration picks for this graph (ProblemAnalyzer + OptimizationSelector)."""
+    c = L.BlockConfig()
+    src, tgt = _i32(source), _i32(target)
+    L.check(L.lib().mcf_block_config_auto(C.byref(c), node_count, src.shape[0], src, tgt))
+    return c
+
+
 class SolutionValidator:
     """The reference's SolutionValidator checks as device reductions (mcf_validator_* of include/mcf_hip.h)."""
 
@@ -295,9 +333,9 @@ class PivotEngine:
     """Device-resident SoA + pivot rules (mcf_engine_* of include/mcf_hip.h)."""
 
     def __init__(self, node_count: int, arc_capacity: int, search_arc_num: int, rule=PivotRule.BlockSearch,
-                 optimized=True, int_width=64, block_size=0, device=0, shard=(0, 0), scan_workgroups=0, flags=0):
+                 optimized=True, int_width=64, block_size=0, device=0, shard=(0, 0), scan_workgroups=0, flags=0, resident_workgroups=0):
         d = L.EngineDesc(node_count, arc_capacity, search_arc_num, int_width, rule, L.SEM_OPTIMIZED if optimized else L.SEM_PLAIN,
-                         block_size, device, shard[0], shard[1], scan_workgroups, flags)
+                         block_size, device, shard[0], shard[1], scan_workgroups, flags, resident_workgroups)
         self._h = C.c_void_p()
         L.check(L.lib().mcf_engine_create(C.byref(self._h), C.byref(d)))
         self.node_count, self.arc_capacity, self.search_arc_num = node_count, arc_capacity, search_arc_num
@@ -344,6 +382,11 @@ class PivotEngine:
         L.check(L.lib().mcf_engine_search_end(self._h, C.byref(f), C.byref(a), C.byref(c)))
         return bool(f.value), a.value, c.value
 
+    def search_end_local(self) -> L.Candidate:
+        c = L.Candidate()
+        L.check(L.lib().mcf_engine_search_end_local(self._h, C.byref(c)))
+        return c
+
     def find_entering_local(self) -> L.Candidate:
         c = L.Candidate()
         L.check(L.lib().mcf_engine_find_entering_local(self._h, C.byref(c)))
@@ -367,6 +410,9 @@ class PivotEngine:
     def block_size(self) -> int:
         v = C.c_int32(); L.check(L.lib().mcf_engine_get_block_size(self._h, C.byref(v))); return v.value
 
+    def set_block_config(self, config, graph_node_count: int):
+        L.check(L.lib().mcf_engine_set_block_config(self._h, C.byref(config), graph_node_count))
+
     def download_pi(self) -> np.ndarray:
         out = np.empty(self.node_count, np.int64); L.check(L.lib().mcf_engine_download_pi(self._h, out)); return out
 
@@ -386,6 +432,28 @@ class PivotEngine:
         avg, mn = C.c_double(), C.c_double()
         L.check(L.lib().mcf_engine_bench_scan(self._h, reps, int(cold), flush_bytes, C.byref(avg), C.byref(mn)))
         return avg.value, mn.value
+
+
+class HostExchange:
+    """mcf_exchange_*: all-gather of the 16-byte candidates between the ranks of one node through POSIX shared memory."""
+
+    def __init__(self, name: str, rank: int, world: int):
+        self.world = world
+        self._h = C.c_void_p()
+        L.check(L.lib().mcf_exchange_open(C.byref(self._h), name.encode(), rank, world))
+
+    def all_gather(self, mine: "L.Candidate"):
+        out = (L.Candidate * self.world)()
+        L.check(L.lib().mcf_exchange_all_gather(self._h, C.byref(mine), out))
+        return list(out)
+
+    def close(self):
+        if self._h:
+            L.lib().mcf_exchange_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
 
 
 def shard_range(search_arc_num: int, rank: int, world: int):

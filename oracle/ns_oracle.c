@@ -5,11 +5,16 @@
  * the checker for the HIP path (tests/, __graft_entry__.smoke(), bench.py's
  * cpu_baseline leg).  Nothing under mincostflow_amd/ may call into this file.
  *
- * Parity is PINNED (see oracle/README.md, tests/test_oracle_*.py):
- *   - LEMON mode is checked pivot-for-pivot against the bundled LEMON 1.3.1 compiled
- *     from /root/reference (oracle/_ref/lemon_driver, built by oracle/Makefile);
- *   - all modes are checked against the reference's .sol optimal costs, the C# unit
- *     test known answers and LEMON's 21-case min_cost_flow_test table.
+ * What pins this restatement (tests/test_oracle_golden.py):
+ *   - the optimal COSTS of the reference's 37 .sol fixtures and 2 csv rows, in every mode and rule;
+ *   - the exact FLOWS of the C# unit tests (NetworkSimplexTests.cs, OptimizationTests.cs) and
+ *     LEMON's 21-case status / cost table (min_cost_flow_test.cc);
+ *   - the README example (Infeasible as written, 71 with supply 13).
+ * What nothing the reference holds pins: the PIVOT ORDER.  The C# reference has no toolchain in the
+ * image and the vendored LEMON cannot be compiled from its own sources (lemon/config.h is generated
+ * by its CMake build), so there is no oracle/_ref.  Pivot-for-pivot parity of the HIP path is parity
+ * with this file's reading of the C# source; LEMON-mode internals that do not change the optimum
+ * (arc mixing order, heuristic initial pivots) are pinned by costs and statuses only.
  *
  * Three semantics modes (differences D1-D13):
  *   NSO_SEM_LEMON      lemon-1.3.1/lemon/network_simplex.h (run(), arc mixing, EQ/LEQ/GEQ
@@ -25,10 +30,12 @@
  * lemon-1.3.1/lemon/network_simplex.h, "BSPO.cs" means
  * src/MinCostFlow.Core/Lemon/Algorithms/Internal/BlockSearchPivotOptimized.cs.
  */
+#define _POSIX_C_SOURCE 199309L   /* clock_gettime under -std=c11 */
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <time.h>
 
 #define NSO_API __attribute__((visibility("default")))
 
@@ -60,6 +67,14 @@ typedef struct ns_oracle {
     int64_t delta;
     /* pivot-rule state */
     int next_arc, block_size, block_size_req;
+    /* OptimizationConfig (OptimizationTypes.cs:24-38), consumed by the plain C# BlockSearchPivot only */
+    int cfg_flags, cfg_min_block, cfg_max_block, cfg_consec;
+    double cfg_ratio, cfg_grow, cfg_shrink, cfg_low, cfg_high;
+    int auto_config;                 /* NS.cs:90 _useAutoConfiguration (the oracle's default is OFF; tests switch it on) */
+    int dyn_min_block, low_hits, high_hits, initial_block_size, would_cache;
+    int64_t arcs_checked;            /* SolverMetrics.TotalArcsChecked, NS.cs:286-290 */
+    int timing;                      /* the reference's three stopwatches (NS.cs:95-98, :285-289, :330-339), off unless asked for */
+    double t_search, t_tree, t_pot;  /* ns */
     int status, initialized;
     int64_t pivots, init_pivots, max_iter;
     int64_t last_sigma;
@@ -112,7 +127,51 @@ NSO_API ns_oracle *nso_create(int n, int m, const int32_t *src, const int32_t *t
     o->vinf = (semantics == NSO_SEM_LEMON) ? INT64_MAX       /* ns.h:653-654 (integer: MAX) */
                                            : INT64_MAX / 2;  /* NS.cs:127 */
     o->status = NSO_NOT_SOLVED;
+    /* new OptimizationConfig(): OptimizationTypes.cs:26-37 */
+    o->cfg_flags = 0; o->cfg_max_block = 100; o->cfg_min_block = 25; o->cfg_grow = 1.2; o->cfg_shrink = 0.8;
+    o->cfg_low = 0.05; o->cfg_high = 0.3; o->cfg_consec = 3; o->cfg_ratio = 0.125;
     return o;
+}
+
+/* SetOptimizationConfig (NS.cs:557-561): replaces the configuration and switches auto-configuration off */
+NSO_API void nso_set_config(ns_oracle *o, int flags, int min_block, int max_block, int consec, double ratio,
+                            double grow, double shrink, double low, double high)
+{
+    o->cfg_flags = flags; o->cfg_min_block = min_block; o->cfg_max_block = max_block; o->cfg_consec = consec;
+    o->cfg_ratio = ratio; o->cfg_grow = grow; o->cfg_shrink = shrink; o->cfg_low = low; o->cfg_high = high;
+    o->auto_config = 0;
+}
+/* SetAutoConfiguration (NS.cs:567-570) */
+NSO_API void nso_set_auto_config(ns_oracle *o, int enable) { o->auto_config = enable; }
+
+enum { OPT_ADAPTIVE = 1, OPT_SMALL_DENSE = 2, OPT_CACHING = 4 };   /* OptimizationTypes.cs:12-14 */
+
+/* NS.cs:237-242: ProblemAnalyzer.Analyze (ProblemAnalyzer.cs:21-106) + OptimizationSelector.SelectConfiguration
+ * (OptimizationSelector.cs:14-95), the fields BlockSearchPivot and CreatePivotRuleFinder read. */
+static void auto_configure(ns_oracle *o)
+{
+    int n = o->n, m = o->m;
+    long long max_possible = (long long)n * (n - 1);
+    double density = max_possible > 0 ? (double)m / max_possible : 0;        /* ProblemAnalyzer.cs:35-36 */
+    int *deg = calloc(n > 0 ? n : 1, sizeof(int));
+    for (int e = 0; e < m; e++) { deg[o->osrc[e]]++; deg[o->otgt[e]]++; }     /* :68-75 out + in */
+    int total = 0;
+    for (int v = 0; v < n; v++) total += deg[v];
+    double avg = n > 0 ? (double)total / n : 0, var = 0;                      /* :80-92 */
+    if (n > 0) { for (int v = 0; v < n; v++) { double d = deg[v] - avg; var += d * d; } var /= n; }
+    double cv = avg > 0 ? sqrt(var) / avg : 0;                                /* :97 */
+    free(deg);
+    int dense = density > 0.01 || m > 10000, sparse = density < 0.005;        /* :58-60 */
+    /* OptimizationSelector.cs:16-95 starts from a fresh OptimizationConfig */
+    o->cfg_flags = 0; o->cfg_grow = 1.2; o->cfg_shrink = 0.8; o->cfg_consec = 3;
+    if (dense) { o->cfg_flags |= OPT_SMALL_DENSE; o->cfg_min_block = 10; o->cfg_max_block = 50; }
+    else { o->cfg_min_block = 25; o->cfg_max_block = 100; }
+    if (cv > 0.5) { o->cfg_flags |= OPT_ADAPTIVE; o->cfg_grow = 1.3; o->cfg_shrink = 0.7; o->cfg_consec = 2; }
+    else if (cv > 0.3) o->cfg_flags |= OPT_ADAPTIVE;
+    if (sparse && m < 50000) o->cfg_flags |= OPT_CACHING;
+    o->cfg_low = m > 10000 ? 0.03 : 0.05;
+    o->cfg_high = m > 10000 ? 0.25 : 0.3;
+    o->cfg_ratio = m > 100000 ? 0.0625 : (m > 10000 ? 0.125 : 0.25);
 }
 
 /* ------------------------------------------------------------------ numbering */
@@ -302,15 +361,31 @@ static void init_rule(ns_oracle *o)
 {
     o->next_arc = 0;
     int base = (int)sqrt((double)o->search_arc_num);
-    if (o->block_size_req > 0) { o->block_size = o->block_size_req; return; }
+    o->low_hits = o->high_hits = 0; o->arcs_checked = 0; o->would_cache = 0;
     if (o->sem == NSO_SEM_CSHARP) {
-        /* NS.cs:1304-1336 with the default OptimizationConfig (OptimizationTypes.cs:24-38:
-         * Flags None, MinBlockSize 25, MinBlockSizeRatio 0.125) and auto-configuration off */
-        int dyn_min = (int)(base * 0.125); if (dyn_min < 25) dyn_min = 25;
-        o->block_size = base > dyn_min ? base : dyn_min;
+        /* NS.cs:1304-1336 (BlockSearchPivot constructor) with the configuration in force */
+        if (o->auto_config) auto_configure(o);
+        o->dyn_min_block = (int)(base * o->cfg_ratio);
+        if (o->dyn_min_block < o->cfg_min_block) o->dyn_min_block = o->cfg_min_block;
+        int b = base;
+        if (o->cfg_flags & OPT_SMALL_DENSE) {
+            double density = (double)o->search_arc_num / o->n;
+            if (density > 10) b = base / 4 < 50 ? base / 4 : 50;
+        }
+        if (b < o->dyn_min_block) b = o->dyn_min_block;
+        o->block_size = o->block_size_req > 0 ? o->block_size_req : b;
+        if (o->rule == NSO_RULE_BLOCK && (o->cfg_flags & OPT_CACHING)) {
+            /* NS.cs:855-883: the reference would hand the search to CachedBlockSearchPivot here (not restated: SURVEY.md 8a, a8) */
+            int nn = (int)((unsigned)o->n * (unsigned)o->n);
+            double d2 = (double)o->search_arc_num / nn;
+            o->would_cache = d2 < 0.01 && o->search_arc_num < 10000;
+        }
+    } else if (o->block_size_req > 0) {
+        o->block_size = o->block_size_req;
     } else {
         o->block_size = base > 10 ? base : 10;             /* ns.h:369-374, BSPO.cs:27-28 */
     }
+    o->initial_block_size = o->block_size;
 }
 
 NSO_API int nso_init(ns_oracle *o)
@@ -357,23 +432,46 @@ static int find_first(ns_oracle *o)
     return 0;
 }
 
-/* ns.h:378-409 and NS.cs:1339-1441: one continuous cyclic scan, next_arc = last scanned arc */
+/* ns.h:378-409 and NS.cs:1339-1441: one continuous cyclic scan, next_arc = last scanned arc.
+ * C# only: arcsChecked (NS.cs:1345-1372) and the adaptive block size (NS.cs:1400-1438). */
 static int find_block_plain(ns_oracle *o)
 {
-    int64_t min = 0; int cnt = o->block_size, e, best = -1;
+    int64_t min = 0; int cnt = o->block_size, e, best = -1, checked = 0;
     for (e = o->next_arc; e < o->search_arc_num; e++) {
+        checked++;
         int64_t c = rc(o, e);
         if (c < min) { min = c; best = e; }
         if (--cnt == 0) { if (min < 0) goto search_end; cnt = o->block_size; }
     }
     for (e = 0; e < o->next_arc; e++) {
+        checked++;
         int64_t c = rc(o, e);
         if (c < min) { min = c; best = e; }
         if (--cnt == 0) { if (min < 0) goto search_end; cnt = o->block_size; }
     }
-    if (min >= 0) return 0;
+    if (min >= 0) { if (o->sem == NSO_SEM_CSHARP) o->arcs_checked += checked; return 0; }   /* NS.cs:290 adds the count either way */
 search_end:
+    if (o->sem == NSO_SEM_CSHARP) o->arcs_checked += checked;
     o->next_arc = e; o->in_arc = best;
+    if (o->sem == NSO_SEM_CSHARP && (o->cfg_flags & OPT_ADAPTIVE)) {
+        int scanned = checked;
+        double hit = scanned > 0 ? 1.0 / scanned : 0;
+        if (hit < o->cfg_low) {
+            o->high_hits = 0; o->low_hits++;
+            if (o->low_hits >= o->cfg_consec) {
+                int ns = (int)(o->block_size * o->cfg_shrink);
+                o->block_size = ns > o->dyn_min_block ? ns : o->dyn_min_block;
+                o->low_hits = 0;
+            }
+        } else if (hit > o->cfg_high) {
+            o->low_hits = 0; o->high_hits++;
+            if (o->high_hits >= o->cfg_consec) {
+                int ns = (int)(o->block_size * o->cfg_grow);
+                o->block_size = ns < o->cfg_max_block ? ns : o->cfg_max_block;
+                o->high_hits = 0;
+            }
+        } else { o->low_hits = 0; o->high_hits = 0; }
+    }
     return 1;
 }
 
@@ -401,14 +499,23 @@ static int find_block_opt(ns_oracle *o)
     return 1;
 }
 
+static double now_ns(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e9 * (double)ts.tv_sec + (double)ts.tv_nsec;
+}
+
 NSO_API int nso_find_entering(ns_oracle *o, int32_t *in_arc)
 {
     int found;
+    double t0 = o->timing ? now_ns() : 0;       /* NS.cs:285-289 */
     switch (o->rule) {
     case NSO_RULE_BEST:  found = find_best(o); break;
     case NSO_RULE_FIRST: found = find_first(o); break;
     default: found = (o->sem == NSO_SEM_CSHARP_OPT) ? find_block_opt(o) : find_block_plain(o); break;
     }
+    if (o->timing) o->t_search += now_ns() - t0;
     if (found && in_arc) *in_arc = o->in_arc;
     return found;
 }
@@ -544,7 +651,14 @@ NSO_API int nso_apply_pivot(ns_oracle *o, int32_t in_arc)
     else if (!change && o->delta == 0) return NSO_UNBOUNDED;                          /* NS.cs:321-325 (D7) */
     change_flow(o, change);
     o->last_subtree = 0; o->last_sigma = 0;
-    if (change) { update_tree(o); update_potential(o); }
+    if (change && !o->timing) { update_tree(o); update_potential(o); }
+    else if (change) {               /* NS.cs:330-339: tree update and potential update are timed separately */
+        double t0 = now_ns();
+        update_tree(o);
+        double t1 = now_ns();
+        update_potential(o);
+        o->t_tree += t1 - t0; o->t_pot += now_ns() - t1;
+    }
     o->pivots++;
     return 0;
 }
@@ -699,6 +813,13 @@ NSO_API int64_t nso_init_pivot_count(const ns_oracle *o) { return o->init_pivots
 NSO_API int nso_search_arc_num(const ns_oracle *o) { return o->search_arc_num; }
 NSO_API int nso_all_arc_num(const ns_oracle *o) { return o->all_arc_num; }
 NSO_API int nso_block_size(const ns_oracle *o) { return o->block_size; }
+NSO_API int nso_initial_block_size(const ns_oracle *o) { return o->initial_block_size; }
+NSO_API int nso_config_flags(const ns_oracle *o) { return o->cfg_flags; }
+NSO_API int nso_would_cache(const ns_oracle *o) { return o->would_cache; }
+NSO_API int64_t nso_arcs_checked(const ns_oracle *o) { return o->arcs_checked; }
+/* SolverMetrics' three phase buckets (OptimizationTypes.cs:45-52), in microseconds; collected only after nso_enable_timing(o, 1) */
+NSO_API void nso_enable_timing(ns_oracle *o, int on) { o->timing = on; }
+NSO_API void nso_phase_us(const ns_oracle *o, double out[3]) { out[0] = o->t_search / 1e3; out[1] = o->t_tree / 1e3; out[2] = o->t_pot / 1e3; }
 NSO_API int nso_next_arc(const ns_oracle *o) { return o->next_arc; }
 NSO_API int64_t nso_art_cost(const ns_oracle *o) { return o->art_cost; }
 NSO_API int nso_last_subtree(const ns_oracle *o) { return o->last_subtree; }

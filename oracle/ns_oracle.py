@@ -52,11 +52,15 @@ def lib():
     L.nso_finish.argtypes = [C.c_void_p]
     L.nso_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.nso_run_pivots.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.nso_set_config.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.nso_set_auto_config.argtypes = [C.c_void_p, C.c_int]
+    L.nso_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    L.nso_phase_us.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     for f in ("nso_status", "nso_search_arc_num", "nso_all_arc_num", "nso_block_size", "nso_next_arc",
-              "nso_last_subtree"):
+              "nso_last_subtree", "nso_initial_block_size", "nso_config_flags", "nso_would_cache"):
         getattr(L, f).argtypes = [C.c_void_p]
         getattr(L, f).restype = C.c_int
-    for f in ("nso_pivots", "nso_init_pivot_count", "nso_art_cost", "nso_total_cost", "nso_last_sigma"):
+    for f in ("nso_pivots", "nso_init_pivot_count", "nso_art_cost", "nso_total_cost", "nso_last_sigma", "nso_arcs_checked"):
         getattr(L, f).argtypes = [C.c_void_p]
         getattr(L, f).restype = C.c_int64
     L.nso_get_flow.argtypes = [C.c_void_p, _i64p]
@@ -103,12 +107,23 @@ class Oracle:
     """One network-simplex run of the CPU restatement."""
 
     def __init__(self, p: Problem, semantics=SEM_CSHARP, rule=RULE_BLOCK, supply_type=GEQ,
-                 arc_mixing=True, block_size=0):
+                 arc_mixing=True, block_size=0, auto_config=False, config=None):
+        """auto_config: the reference's SetAutoConfiguration (its default is ON; the oracle's default is OFF so that the
+        plain rule runs with `new OptimizationConfig()`).  config: dict of OptimizationConfig fields (SetOptimizationConfig)."""
         self.p = p
         self.L = lib()
         self.h = self.L.nso_create(p.n, p.m, p.src, p.tgt, p.lower, p.upper, p.cost, p.supply,
                                    semantics, rule, supply_type, int(arc_mixing), block_size)
         self.semantics, self.rule = semantics, rule
+        if config is not None:
+            c = dict(flags=0, min_block_size=25, max_block_size=100, consecutive_hits_before_adapt=3, min_block_size_ratio=0.125,
+                     block_size_growth_factor=1.2, block_size_shrink_factor=0.8, low_hit_rate_threshold=0.05, high_hit_rate_threshold=0.3)
+            c.update(config)
+            self.L.nso_set_config(self.h, c["flags"], c["min_block_size"], c["max_block_size"], c["consecutive_hits_before_adapt"],
+                                  c["min_block_size_ratio"], c["block_size_growth_factor"], c["block_size_shrink_factor"],
+                                  c["low_hit_rate_threshold"], c["high_hit_rate_threshold"])
+        if auto_config:
+            self.L.nso_set_auto_config(self.h, 1)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -159,6 +174,14 @@ class Oracle:
     @property
     def block_size(self): return self.L.nso_block_size(self.h)
     @property
+    def initial_block_size(self): return self.L.nso_initial_block_size(self.h)
+    @property
+    def config_flags(self): return self.L.nso_config_flags(self.h)
+    @property
+    def would_cache(self): return bool(self.L.nso_would_cache(self.h))
+    @property
+    def arcs_checked(self): return self.L.nso_arcs_checked(self.h)
+    @property
     def next_arc(self): return self.L.nso_next_arc(self.h)
     @property
     def pivots(self): return self.L.nso_pivots(self.h)
@@ -168,6 +191,15 @@ class Oracle:
     def last_subtree(self): return self.L.nso_last_subtree(self.h)
     @property
     def last_sigma(self): return self.L.nso_last_sigma(self.h)
+
+    def enable_timing(self, on=True):
+        self.L.nso_enable_timing(self.h, int(on))
+
+    def phase_us(self):
+        """(pivot search, tree update, potential update) in microseconds: the reference's SolverMetrics buckets."""
+        out = (C.c_double * 3)()
+        self.L.nso_phase_us(self.h, out)
+        return tuple(out)
 
     def flow(self):
         out = np.empty(self.p.m, np.int64); self.L.nso_get_flow(self.h, out); return out

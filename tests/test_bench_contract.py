@@ -45,3 +45,28 @@ def test_bench_prints_one_contract_line():
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     _check(json.loads(lines[0]), with_cpu=False)
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    """`--gpus N` never labels a run with another number of ranks (no GPU needed: the check comes before anything touches one)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "refusing" in out.stderr and not out.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_spawns_its_ranks_and_runs_the_sharded_leg():
+    """`python bench.py --gpus 2 --backend gloo` without a launcher starts two ranks itself (both on this box's one GPU), prints n_gpus 2 and
+    times the arc-sharded config-5 leg with two shard engines exchanging their candidates through shared memory."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                          "--sharded-pivots", "300"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    _check(line, with_cpu=False)
+    assert line["n_gpus"] == 2
+    sh = line["sharded"]
+    assert sh["ranks"] == 2 and sh["variants"]["host_exchange"]["ranks"] == 2 and sh["variants"]["host_exchange"]["pivots"] == 300
+    assert sh["identical_pivot_sequence"] is True and sh["single_gpu_same_pivots"]["pivots"] == 300

@@ -1,5 +1,7 @@
 """Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
 Bit-exact: this is integer work.  Run with `pytest -m gpu` on an MI355X."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -123,11 +125,17 @@ def test_scan_edge_cases():
     assert ei.value.code == L.ERR_INVALID
 
 
-def _solve_both(p, sem, rule, int_width=0, flags=0, supply_type=O.GEQ, block_size=0):
-    o = O.Oracle(p, sem, rule, supply_type=supply_type, block_size=block_size)
+def _solve_both(p, sem, rule, int_width=0, flags=0, supply_type=O.GEQ, block_size=0, auto=True, config=None):
+    """auto: the reference's auto-configuration (its default, NetworkSimplex.cs:90) on both sides; config: dict of OptimizationConfig
+    fields given to SetOptimizationConfig on both sides (switches auto-configuration off, NetworkSimplex.cs:557-561)."""
+    o = O.Oracle(p, sem, rule, supply_type=supply_type, block_size=block_size, auto_config=auto and config is None, config=config)
     st_o, tr_o = o.solve(trace_cap=4_000_000)
     ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
     ns.set_pivot_rule(RULES[rule]).enable_optimized_pivot(sem == O.SEM_CSHARP_OPT).set_supply_type(supply_type)
+    if config is not None:
+        ns.set_optimization_config(M.block_config(**config))
+    elif not auto:
+        ns.set_auto_configuration(False)
     ns.set_device(0, int_width, block_size, flags).record_trace(4_000_000)
     st = ns.solve()
     return o, st_o, tr_o, ns, st
@@ -151,7 +159,14 @@ def test_solve_is_pivot_for_pivot_identical(name, mode):
         assert ns.get_total_cost() == o.total_cost
         assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
         m = ns.get_metrics()
-        assert m["iterations"] == o.n_pivots and m["block_size"] == o.block_size and m["search_arc_num"] == o.search_arc_num
+        assert m["iterations"] == o.n_pivots and m["block_size"] == o.initial_block_size and m["search_arc_num"] == o.search_arc_num
+        # the rest of SolverMetrics (OptimizationTypes.cs:53-59): only the plain BlockSearchPivot counts arcs and reports block sizes
+        assert m["total_arcs_checked"] == o.arcs_checked and m["config_flags"] == (o.config_flags if sem == O.SEM_CSHARP else m["config_flags"])
+        if sem == O.SEM_CSHARP and rule == O.RULE_BLOCK:
+            assert (m["initial_block_size"], m["final_block_size"]) == (o.initial_block_size, o.block_size)
+            assert m["reference_selects_cached_pivot"] == int(o.would_cache)
+        else:
+            assert (m["initial_block_size"], m["final_block_size"], m["total_arcs_checked"]) == (0, 0, 0)
         assert m["engine"]["resident"] == (0 if mode == M.ENGINE_DISPATCH else 1)
         if mode == M.ENGINE_CANDIDATES and rule == O.RULE_BEST and 2 * o.search_arc_num <= 24 * (p.n + 1):
             assert m["engine"]["candidates"] == 1 and m["engine"]["host_decided"] + m["engine"]["resident_requests"] >= o.n_pivots
@@ -595,3 +610,209 @@ def test_search_in_two_halves(mode):
         eng.append_potential(nodes, a["pi"][nodes])
     assert np.array_equal(eng.download_pi(), a["pi"])
     assert np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [pytest.param(0, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"), pytest.param(M.ENGINE_SHARE_DEVICE, id="resident-shared")])
+@pytest.mark.parametrize("m_s,n", [(400003, 100001), (60001, 16000)])
+def test_state_patch_lists_of_any_length(mode, m_s, n):
+    """mcf_engine_patch_state with 65, 200 and 5000 distinct arcs between two searches, each time with a potential list pending
+    ('Queued; ordered before the next search', include/mcf_hip.h): the resident grid receives them through the mailbox (up to 4096)
+    or, beyond that, is stopped first; dispatch mode ships them with update_kernel."""
+    rng = np.random.default_rng(2024 + m_s)
+    a = _random_soa(rng, m_s, n, 3, 9)
+    eng = M.PivotEngine(n, len(a["src"]), m_s, rule=M.PivotRule.BestEligible, optimized=True, flags=mode)
+    eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+    for it, k_st in enumerate([65, 3, 200, 5000, 64, 4097, 1]):
+        f, e, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+        f2, e2, c2 = eng.find_entering()
+        assert f2 == f and (not f or (e2, c2) == (e, c)), (it, k_st, e2, e, c2, c)
+        nodes = rng.choice(n, size=int(rng.choice([1, 7, 300, 5000])), replace=False).astype(np.int32)
+        a["pi"][nodes] += int(rng.integers(-4, 5))
+        if it % 2:
+            eng.set_potential(nodes, a["pi"][nodes])      # potentials first, states after ...
+        arcs = rng.choice(m_s, size=k_st, replace=False).astype(np.int32)
+        vals = rng.integers(-1, 2, k_st).astype(np.int8)
+        a["state"][arcs] = vals
+        # in several calls, repeating some arcs with their final value
+        cut = k_st // 3
+        eng.patch_state(arcs[:cut], vals[:cut])
+        eng.patch_state(arcs[cut:], vals[cut:])
+        eng.patch_state(arcs[:2], vals[:2])
+        if not it % 2:
+            eng.set_potential(nodes, a["pi"][nodes])      # ... or the other way round
+    f, e, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+    assert eng.find_entering() == (f, e, c)
+    assert np.array_equal(eng.download_pi(), a["pi"])
+    assert np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [pytest.param(0, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch")])
+@pytest.mark.parametrize("name", ["netgen_8_10a", "transport_40x30", "circulation_100_0_10", "AURV19V6", "netgen_8_13a"])
+def test_block_search_sizing_of_the_reference_default(name, mode):
+    """`new NetworkSimplex(g).Solve()`: plain Block Search, auto-configured (SmallBlocksForDense, adaptive block size) -- and the same
+    rule under explicit configurations, including one that makes the block GROW.  Pivot for pivot, block size for block size."""
+    p = load(name)
+    cases = [dict(auto=True), dict(auto=False),
+             dict(config=dict(flags=1)), dict(config=dict(flags=3, min_block_size=10, max_block_size=50)),
+             dict(config=dict(flags=1, low_hit_rate_threshold=0.001, high_hit_rate_threshold=0.002, max_block_size=400, block_size_growth_factor=1.3))]
+    if name == "netgen_8_13a":
+        cases = cases[:1]
+    for kw in cases:
+        o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP, O.RULE_BLOCK, flags=mode, **kw)
+        assert st == st_o == O.OPTIMAL, (name, kw)
+        assert np.array_equal(ns.trace(), tr_o), (name, kw, int(np.argmax(ns.trace()[: len(tr_o)] != tr_o[: len(ns.trace())])))
+        assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
+        m = ns.get_metrics()
+        assert (m["initial_block_size"], m["final_block_size"]) == (o.initial_block_size, o.block_size), (name, kw)
+        assert m["total_arcs_checked"] == o.arcs_checked and m["config_flags"] == o.config_flags
+        assert abs(m["average_arcs_checked_per_pivot"] - o.arcs_checked / max(o.n_pivots, 1)) < 1e-9
+    # EnableOptimizedPivot(true) ignores the configuration (BlockSearchPivotOptimized.cs:27-28)
+    o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, O.RULE_BLOCK, flags=mode, config=dict(flags=3, min_block_size=10))
+    assert st == st_o == O.OPTIMAL and np.array_equal(ns.trace(), tr_o)
+
+
+@pytest.mark.gpu
+def test_raw_engine_adapts_its_block_size_per_request():
+    """PivotEngine + set_block_config on random arrays: every search travels with its own block size (resident mailbox / kernel arguments)."""
+    rng = np.random.default_rng(515)
+    m_s, n = 90001, 20000
+    for mode in (0, M.ENGINE_DISPATCH):
+        a = _random_soa(rng, m_s, n, 40, 400, extra=0)
+        cfg = dict(flags=1, consecutive_hits_before_adapt=1, block_size_shrink_factor=0.6, min_block_size=7, min_block_size_ratio=0.0)
+        eng = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BlockSearch, optimized=False, flags=mode)
+        c = M.block_config(**cfg)
+        eng.set_block_config(c, n - 1)
+        block, dmin = C.c_int32(), C.c_int32()
+        L.check(L.lib().mcf_block_initial_size(C.byref(c), m_s, n - 1, C.byref(block), C.byref(dmin)))
+        counters = (C.c_int32 * 2)(0, 0)
+        eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+        next_arc, seen = 0, set()
+        for it in range(25):
+            assert eng.block_size == block.value
+            seen.add(block.value)
+            f, e, c_, na = _oracle_scan(O.RULE_BLOCK, False, a, m_s, block.value, next_arc)
+            f2, e2, c2 = eng.find_entering()
+            assert (f2, e2, c2) == (f, e, c_), (it, block.value)
+            assert eng.next_arc == na
+            # arcs the reference loop examined: from next_arc to the new next_arc inclusive, cyclically
+            checked = (na - next_arc) % m_s + 1 if na != next_arc else (1 if block.value == 1 else m_s)
+            L.check(L.lib().mcf_block_adapt(C.byref(c), dmin.value, checked, C.byref(block), counters))
+            next_arc = na
+            a["state"][e] = 0
+            eng.patch_state([e], [0])
+        assert len(seen) > 3 and eng.stats()["arcs_checked"] > 0
+
+
+# ------------------------------------------------------------------ arc shards: resident shard engines, in-process shard groups, BASELINE config 5
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rule,optimized", [(O.RULE_BEST, True), (O.RULE_BLOCK, True), (O.RULE_BLOCK, False), (O.RULE_FIRST, True)])
+def test_resident_shard_engines_resolve_like_one_engine(rule, optimized):
+    """The shard test above with every shard served by its own RESIDENT grid (co-resident on this GPU: MCF_ENGINE_SHARE_DEVICE and a
+    grid cap), searches posted to all shards first and collected afterwards (mcf_engine_search_begin / _search_end_local)."""
+    rng = np.random.default_rng(199 + rule)
+    m_s, n, world = 150_011, 30_000, 3
+    a = _random_soa(rng, m_s, n, 5, 12, extra=0)
+    block = 173
+    one = M.PivotEngine(n, m_s, m_s, rule=RULES[rule], optimized=optimized, block_size=block, flags=M.ENGINE_DISPATCH)
+    one.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+    shards = []
+    for r in range(world):
+        e = M.PivotEngine(n, m_s, m_s, rule=RULES[rule], optimized=optimized, block_size=block, shard=M.shard_range(m_s, r, world),
+                          flags=M.ENGINE_SHARE_DEVICE, resident_workgroups=64)
+        e.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+        assert e.stats()["resident"] == 1
+        shards.append(e)
+    for it in range(12):
+        want = one.find_entering()
+        for e in shards:
+            e.search_begin()
+        cands = [e.search_end_local() for e in shards]
+        got = [e.resolve(cands) for e in shards]
+        assert all(g == want for g in got), (it, want, got)
+        assert all(e.next_arc == one.next_arc for e in shards)
+        if want[0]:
+            arcs = np.array([want[1], int(rng.integers(0, m_s))], np.int32); vals = np.array([0, int(rng.integers(-1, 2))], np.int8)
+            nodes = rng.choice(n, size=int(rng.choice([1, 40, 3000])), replace=False).astype(np.int32)
+            for e in [one] + shards:
+                e.patch_state(arcs, vals)
+                e.update_potential(nodes, -3)
+    st = [e.stats() for e in shards]
+    assert all(x["resident_requests"] >= 12 for x in st)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_shard_group_solves_pivot_for_pivot(shards):
+    """mcf_ns_set_shard_group: one host thread, R engines (here co-resident on one GPU) each holding an arc shard, host-side MINLOC over
+    their answers -- the pivot sequence of the un-sharded solve, for Best Eligible and both Block Search flavours (the plain one with the
+    reference's adaptive block size, which every shard has to follow in step)."""
+    cases = [(load("netgen_8_14a"), [(O.SEM_CSHARP_OPT, O.RULE_BEST)]),
+             (None, [(O.SEM_CSHARP_OPT, O.RULE_BEST), (O.SEM_CSHARP_OPT, O.RULE_BLOCK), (O.SEM_CSHARP, O.RULE_BLOCK)])]
+    g = M.netgen_like(7, 20_000, 60_000, 100, 100)
+    for p, rules in cases:
+        if p is None:
+            p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
+        for sem, rule in rules:
+            o = O.Oracle(p, sem, rule, auto_config=True)
+            st_o, tr_o = o.solve(trace_cap=4_000_000)
+            ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
+            ns.set_pivot_rule(RULES[rule]).enable_optimized_pivot(sem == O.SEM_CSHARP_OPT).record_trace(4_000_000)
+            ns.set_shard_group([0] * shards)
+            assert ns.solve() == st_o == O.OPTIMAL
+            assert np.array_equal(ns.trace(), tr_o), (shards, sem, rule, int(np.argmax(ns.trace()[: len(tr_o)] != tr_o[: len(ns.trace())])))
+            assert ns.get_total_cost() == o.total_cost
+            assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
+            if sem == O.SEM_CSHARP:
+                m = ns.get_metrics()
+                assert (m["initial_block_size"], m["final_block_size"], m["total_arcs_checked"]) == (o.initial_block_size, o.block_size, o.arcs_checked)
+
+
+CONFIG5 = (13502460, 1_000_000, 8_000_000, 1000, 1000)
+
+
+@pytest.mark.gpu
+def test_config5_solves_end_to_end_and_shards_follow_the_same_pivots():
+    """BASELINE.json configs[4] on ONE GPU, end to end: NETGEN-like 1M nodes / 8M arcs, Best Eligible, int64, through mcf_ns_solve with
+    the layout the engine picks by itself at this size (bucketed, one dispatch per search, 2048 records per search).  Checked by
+      * the device validator's optimality certificate (mcf_ns_validate: conservation, bounds, complementary slackness, primal = dual),
+      * the optimal cost of the CPU oracle's Block-Search solve of the same instance (tests/golden/config5_cost.json; 15-20 CPU minutes,
+        hence golden -- generated by tests/golden/make_config5_cost.py),
+      * the oracle's own Best-Eligible pivots for the first 1500 searches, arc for arc,
+      * and the same instance as 2 and 3 arc shards (mcf_ns_set_shard_group on this GPU) for the first 3000 pivots against the
+        un-sharded trace."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5_cost.json")))
+    g = M.netgen_like(*CONFIG5)
+    assert int(g.source.astype(np.int64).sum()) == gold["checksum_source"] and int(g.cost.sum()) == gold["checksum_cost"]      # the same instance
+    keep = 3000
+    ns = M.NetworkSimplex.from_problem(g).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).set_device(0, 64).record_trace(keep)
+    assert ns.solve() == M.SolverStatus.Optimal
+    m = ns.get_metrics()
+    assert m["search_arc_num"] == gold["search_arc_num"] == 9_000_000 and m["iterations"] > 1_000_000
+    assert m["engine"]["resident"] == 0 and m["engine"]["scan_workgroups"] == 2048          # what the engine chooses at this size
+    cost = ns.get_total_cost()
+    assert cost == gold["total_cost"], (cost, gold["total_cost"])
+    v = ns.validate()
+    assert v["valid"] == 1 and v["objective"] == v["dual_cost"] == cost, v
+    trace = ns.trace()
+    assert len(trace) == keep
+    del ns
+    # the oracle's Best Eligible on the same instance: 9M arcs per search on one core, so only the first searches
+    p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
+    o = O.Oracle(p, O.SEM_CSHARP_OPT, O.RULE_BEST)
+    assert o.init()
+    for it in range(1500):
+        f, e = o.find_entering()
+        assert f and e == trace[it], (it, e, int(trace[it]))
+        o.apply_pivot(e)
+    del o
+    for shards in (2, 3):
+        nsg = M.NetworkSimplex.from_problem(g).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).set_device(0, 64)
+        nsg.set_shard_group([0] * shards).set_pivot_limit(keep).record_trace(keep)
+        assert nsg.solve() == M.SolverStatus.NotSolved
+        assert np.array_equal(nsg.trace(), trace), (shards, int(np.argmax(nsg.trace() != trace)))
+        del nsg

@@ -227,3 +227,98 @@ def test_shard_ranges_partition_the_search_arcs():
             assert prev == m_s
     with pytest.raises(M.McfError):
         M.shard_range(10, 2, 2)
+
+
+# ------------------------------------------------------------------ block sizing of the plain BlockSearchPivot (NetworkSimplex.cs:1304-1337, :1400-1438)
+
+def _cfg_dict(c):
+    d = c.as_dict()
+    return d
+
+
+@pytest.mark.parametrize("name,path,want", fixtures(), ids=[f[0] for f in fixtures()])
+def test_auto_configuration_matches_the_oracle_on_every_fixture(name, path, want):
+    """mcf_block_config_auto (ProblemAnalyzer + OptimizationSelector) and mcf_block_initial_size against the oracle's own restatement:
+    same flags, same initial block size, same 'the reference would use the cached finder' verdict."""
+    p = load(path)
+    c = M.auto_block_config(p.n, p.src, p.tgt)
+    o = O.Oracle(p, O.SEM_CSHARP, O.RULE_BLOCK, auto_config=True)
+    if not o.init():
+        pytest.skip("infeasible bounds")
+    assert c.flags == o.config_flags
+    b, dmin = C.c_int32(), C.c_int32()
+    L.check(L.lib().mcf_block_initial_size(C.byref(c), o.search_arc_num, p.n, C.byref(b), C.byref(dmin)))
+    assert b.value == o.initial_block_size == o.block_size
+
+
+def test_block_config_defaults_and_small_blocks():
+    c = M.block_config()
+    assert _cfg_dict(c) == dict(flags=0, min_block_size=25, max_block_size=100, consecutive_hits_before_adapt=3, min_block_size_ratio=0.125,
+                                block_size_growth_factor=1.2, block_size_shrink_factor=0.8, low_hit_rate_threshold=0.05, high_hit_rate_threshold=0.3)
+    b, dmin = C.c_int32(), C.c_int32()
+    # sqrt(40000) = 200; default config: max(200, max(25, 25)) = 200
+    L.check(L.lib().mcf_block_initial_size(C.byref(c), 40000, 10000, C.byref(b), C.byref(dmin)))
+    assert (b.value, dmin.value) == (200, 25)
+    # SmallBlocksForDense: density 40000 / 1000 = 40 > 10 -> min(50, 200 / 4) = 50
+    c = M.block_config(flags=M.OPT_SMALL_BLOCKS_FOR_DENSE)
+    L.check(L.lib().mcf_block_initial_size(C.byref(c), 40000, 1000, C.byref(b), C.byref(dmin)))
+    assert (b.value, dmin.value) == (50, 25)
+    # density exactly 10 is not dense (NetworkSimplex.cs:1318 'density > 10')
+    L.check(L.lib().mcf_block_initial_size(C.byref(c), 40000, 4000, C.byref(b), C.byref(dmin)))
+    assert b.value == 200
+    # tiny search range: the dynamic minimum wins
+    L.check(L.lib().mcf_block_initial_size(C.byref(c), 100, 3, C.byref(b), C.byref(dmin)))
+    assert (b.value, dmin.value) == (25, 25)
+
+
+@pytest.mark.parametrize("name", ["netgen_8_10a", "transport_40x30", "circulation_100_0_10", "AURV19V6"])
+@pytest.mark.parametrize("cfg", [dict(flags=1), dict(flags=3), dict(flags=1, block_size_shrink_factor=0.7, consecutive_hits_before_adapt=2, min_block_size=10),
+                                 dict(flags=1, low_hit_rate_threshold=0.001, high_hit_rate_threshold=0.002, max_block_size=400, block_size_growth_factor=1.3)],
+                         ids=["adaptive", "adaptive+small", "fast-shrink", "growing"])
+def test_adaptive_block_size_follows_the_oracle(name, cfg):
+    """mcf_block_adapt driven with the oracle's per-search arc counts reproduces the oracle's block size after every search of a whole
+    solve (the growing configuration makes the 'found quickly' branch fire, which the defaults never reach)."""
+    p = load(name)
+    o = O.Oracle(p, O.SEM_CSHARP, O.RULE_BLOCK, config=cfg)
+    assert o.init()
+    c = M.block_config(**cfg)
+    b, dmin = C.c_int32(), C.c_int32()
+    L.check(L.lib().mcf_block_initial_size(C.byref(c), o.search_arc_num, p.n, C.byref(b), C.byref(dmin)))
+    assert b.value == o.block_size
+    counters = (C.c_int32 * 2)(0, 0)
+    sizes, before = set(), o.arcs_checked
+    for it in range(200000):
+        f, e = o.find_entering()
+        checked = o.arcs_checked - before
+        before = o.arcs_checked
+        if not f:
+            break
+        L.check(L.lib().mcf_block_adapt(C.byref(c), dmin.value, checked, C.byref(b), counters))
+        assert b.value == o.block_size, (it, checked)
+        sizes.add(b.value)
+        o.apply_pivot(e)
+    assert len(sizes) > 1 or b.value == dmin.value          # the size did move (unless it started at the dynamic minimum)
+    assert o.finish() == O.OPTIMAL
+
+
+def test_auto_configuration_off_equals_the_default_config():
+    p = load("netgen_8_10a")
+    a = O.Oracle(p, O.SEM_CSHARP, O.RULE_BLOCK); a.solve()
+    b = O.Oracle(p, O.SEM_CSHARP, O.RULE_BLOCK, config={}); b.solve()
+    c = O.Oracle(p, O.SEM_CSHARP, O.RULE_BLOCK, auto_config=True); st, _ = c.solve()
+    assert a.pivots == b.pivots and a.total_cost == b.total_cost == c.total_cost and st == O.OPTIMAL
+    assert c.initial_block_size == c.block_size or c.config_flags & 1
+
+
+def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
+    """include/mcf_hip.h compiled as plain C (it is a C ABI) and its struct sizes compared with the ctypes mirrors in _lib.py."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(mcf_engine_stats), sizeof(mcf_ns_metrics),'
+                   ' sizeof(mcf_engine_desc), sizeof(mcf_block_config), sizeof(mcf_candidate), sizeof(mcf_validation));return 0;}\n'
+                   % os.path.join(ROOT, "include", "mcf_hip.h"))
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(t) for t in (L.EngineStats, L.NsMetrics, L.EngineDesc, L.BlockConfig, L.Candidate, L.Validation)]
+    assert got == want

@@ -49,7 +49,7 @@ def _local_candidate(M, L, a, m_s, shard, rule, optimized, block, next_arc):
     return L.Candidate(int(rc[k]), int(pos[k]), int(idx[k]))
 
 
-def _rank_main(rank, world, port, fixture, rule, optimized, out_dir):
+def _rank_main(rank, world, port, fixture, rule, optimized, out_dir, exchange="gloo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -70,13 +70,20 @@ def _rank_main(rank, world, port, fixture, rule, optimized, out_dir):
     shard = M.shard_range(m_s, rank, world)
     block = max(int(np.sqrt(m_s)), 10)
     next_arc, trace = 0, []
+    xchg = None
+    if exchange == "shm":           # the product's host exchange (mcf_exchange_*): POSIX shared memory instead of a collective
+        xchg = M.HostExchange(f"/mcf_test_{port}", rank, world)
+        dist.barrier()              # everybody has opened (and zeroed its slots) before the first exchange
     while True:
         a = ns.internal()
         mine = _local_candidate(M, L, a, m_s, shard, rule, optimized, block, next_arc)
-        send = torch.frombuffer(bytearray(bytes(mine)), dtype=torch.uint8)          # the 16-byte mcf_candidate record
-        got = [torch.zeros(16, dtype=torch.uint8) for _ in range(world)]
-        dist.all_gather(got, send)
-        cands = [L.Candidate.from_buffer_copy(bytes(t.numpy().tobytes())) for t in got]
+        if xchg is not None:
+            cands = xchg.all_gather(mine)
+        else:
+            send = torch.frombuffer(bytearray(bytes(mine)), dtype=torch.uint8)          # the 16-byte mcf_candidate record
+            got = [torch.zeros(16, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(got, send)
+            cands = [L.Candidate.from_buffer_copy(bytes(t.numpy().tobytes())) for t in got]
         found, arc, rc, next_arc = M.resolve_candidates(rule, optimized, m_s, block, next_arc, cands)
         if not found:
             break
@@ -95,6 +102,9 @@ def _rank_main(rank, world, port, fixture, rule, optimized, out_dir):
     dist.all_gather(all_d, digest)
     assert all(torch.equal(all_d[0], d) for d in all_d)
     open(os.path.join(out_dir, f"ok{rank}"), "w").write(str(len(trace)))
+    dist.barrier()
+    if xchg is not None:
+        xchg.close()
     dist.destroy_process_group()
 
 
@@ -106,3 +116,33 @@ def test_two_rank_sharded_solve_over_gloo(tmp_path, fixture, rule, optimized):
     mp.spawn(_rank_main, args=(world, port, fixture, rule, optimized, str(tmp_path)), nprocs=world, join=True)
     counts = [int(open(tmp_path / f"ok{r}").read()) for r in range(world)]
     assert counts[0] == counts[1] > 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_solve_over_the_shared_memory_exchange(tmp_path, world):
+    """The same replicated pivot loop with the candidates exchanged by mcf_exchange_all_gather (what mcf_ns_set_sharding_host uses on the
+    GPU box) instead of a gloo collective: thousands of lock-step exchanges between processes, identical pivots on every rank."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_rank_main, args=(world, port, "netgen_8_08a", 2, True, str(tmp_path), "shm"), nprocs=world, join=True)
+    counts = [int(open(tmp_path / f"ok{r}").read()) for r in range(world)]
+    assert len(set(counts)) == 1 and counts[0] > 0
+
+
+def test_exchange_rejects_bad_arguments_and_survives_a_stale_segment():
+    import mincostflow_amd as M
+    from mincostflow_amd import _lib as L
+    with pytest.raises(M.McfError):
+        M.HostExchange("no-leading-slash", 0, 1)
+    with pytest.raises(M.McfError):
+        M.HostExchange("/mcf_test_bad", 2, 2)
+    name = f"/mcf_test_stale_{os.getpid()}"
+    a = M.HostExchange(name, 0, 1)
+    for k in range(5):
+        got = a.all_gather(L.Candidate(-k, k, k))
+        assert (got[0].reduced_cost, got[0].pos, got[0].arc) == (-k, k, k)
+    # a second user of the same name (the first never closed: a crashed run) starts from a clean slot
+    b = M.HostExchange(name, 0, 1)
+    got = b.all_gather(L.Candidate(-7, 7, 7))
+    assert got[0].arc == 7
+    a.close(); b.close()
