@@ -104,10 +104,12 @@ typedef struct mcf_engine_desc {
 #define MCF_ENGINE_NO_INLINE_UPDATE 4     /* always apply patches with the separate update kernel */
 #define MCF_ENGINE_RESIDENT 8             /* (default behaviour, kept for explicitness) serve searches from ONE resident scan grid fed
                                              through a mailbox in BAR-mapped VRAM instead of one dispatch per search */
-#define MCF_ENGINE_CANDIDATES 32          /* Best Eligible, resident mode, <= 1M search arcs: every device search also returns a candidate
-                                             list that is complete below a threshold; the following searches are answered on the host
-                                             from that list plus the few arcs the pivots touched, whenever that provably is the scan's
-                                             answer (identical pivot sequence, fewer round trips).  Off by default. */
+#define MCF_ENGINE_CANDIDATES 32          /* (default behaviour, kept for explicitness) Best Eligible, resident mode, register-resident arcs, sparse graph
+                                             (2 m_s <= 24 n): every device search also returns a candidate list that is complete below a threshold;
+                                             the following searches are answered on the host from that list plus a heap of the arcs the pivots
+                                             touched, whenever that provably is the scan's answer, and the list is refreshed ahead of need
+                                             (identical pivot sequence, a device round trip for about one search in seven).  DESIGN.md 3.4 */
+#define MCF_ENGINE_NO_CANDIDATES 128      /* every search is a device search */
 #define MCF_ENGINE_SHARE_DEVICE 64        /* several engines use this device at once (independent solves): keep the resident grid's register
                                              and LDS footprint small so that their grids are co-resident on every CU -- the grid then gathers
                                              the potentials for every request instead of keeping them in registers (~0.5 us per search) */
@@ -247,6 +249,7 @@ typedef struct mcf_engine_stats {
     int32_t initial_block_size, current_block_size;
     int32_t comm_ranks;           /* ranks of the RCCL communicator as ncclCommCount reports them (0: no communicator) */
     int32_t reserved;
+    int64_t async_refreshes;      /* candidate lists requested ahead of need (the host kept answering while the device searched) */
 } mcf_engine_stats;
 MCF_API int mcf_engine_get_stats(mcf_engine *e, mcf_engine_stats *out);
 MCF_API int mcf_engine_reset_stats(mcf_engine *e);

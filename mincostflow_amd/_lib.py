@@ -22,6 +22,7 @@ STATE_UPPER, STATE_TREE, STATE_LOWER = -1, 0, 1
 INF_CAP = np.iinfo(np.int64).max
 ENGINE_SAMPLE_KERNEL_TIME, ENGINE_TIME_EVERY_KERNEL, ENGINE_NO_INLINE_UPDATE, ENGINE_RESIDENT, ENGINE_DISPATCH, ENGINE_CANDIDATES = 1, 2, 4, 8, 16, 32
 ENGINE_SHARE_DEVICE = 64
+ENGINE_NO_CANDIDATES = 128
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OVERFLOW, ERR_TIMEOUT, ERR_STATE, ERR_IO, ERR_COMM = -1, -2, -3, -4, -5, -6, -7, -8
 
 
@@ -48,7 +49,7 @@ class EngineStats(C.Structure):
                 ("bytes_per_scan", C.c_int64), ("resident", C.c_int64), ("resident_launches", C.c_int64),
                 ("resident_requests", C.c_int64), ("resident_scan_ns", C.c_double), ("resident_kernel_ns", C.c_double), ("candidates", C.c_int64),
                 ("host_decided", C.c_int64), ("arcs_checked", C.c_int64), ("initial_block_size", C.c_int32), ("current_block_size", C.c_int32),
-                ("comm_ranks", C.c_int32), ("reserved", C.c_int32)]
+                ("comm_ranks", C.c_int32), ("reserved", C.c_int32), ("async_refreshes", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -135,6 +136,7 @@ struct mcf_engine {
     mcf_candidate *d_cand_local = nullptr, *d_cand_all = nullptr, *h_cand_all = nullptr;
     // resident mode (flag MCF_ENGINE_RESIDENT): mailbox in BAR-mapped fine-grained VRAM, exit record in pinned host memory
     bool resident_ok = false, resident_running = false, resident_reg = false;
+    bool has_slot = false;         // this engine's grid occupies one of the device's resident slots (resident_slot_acquire)
     // host-side phase times are counted in time-stamp-counter ticks (a clock call costs 20+ ns, four of them per search) and scaled to ns
     // in mcf_engine_get_stats against the wall clock since creation
     double wait_ticks = 0, launch_ticks = 0, cal_ns = 0, cal_ticks = 0;
@@ -147,26 +149,43 @@ struct mcf_engine {
     uint32_t *mailbox = nullptr;
     int mailbox_lines = 0, mailbox_max_st = 0, poll_replicas = 8, poll_sleep = 1;
     uint32_t prev_seq = 0;
-    // candidate cache (flag MCF_ENGINE_CANDIDATES; Best Eligible, resident, register-resident tiles): see cand_* below
+    // candidate cache (Best Eligible, resident, register-resident tiles, sparse graphs): see cand_* below
     bool cand_on = false, cand_valid = false;
     std::vector<int32_t> h_src, h_tgt;            // host mirrors of the resident arrays (search arcs only)
     std::vector<int64_t> h_cost;
     std::vector<int8_t> h_state;
-    std::vector<int32_t> adj_start, adj_arc;      // arcs incident to each node
-    std::vector<uint32_t> node_mark, arc_mark;    // == cand_epoch: touched since the last device search
-    uint32_t cand_epoch = 1;
-    std::vector<int32_t> dirty_nodes, dirty_arcs;
-    std::vector<int64_t> dirty_vals;              // current potential of dirty_nodes[i]
-    std::vector<int32_t> node_slot;               // position of a marked node in dirty_nodes
-    bool dirty_overflow = false;                  // too much is dirty for the host to answer: only collect patches until the device searches
-    int patch_capacity = 0;                       // potential patches one request / one staged update can carry (2 * node_count + 256)
-    size_t dirty_marked = 0;                      // entries of dirty_nodes that were added with marking (before the overflow)
-    int dirty_blind_appends = 0;                  // lists appended without marking since then
-    int64_t dirty_degree = 0;
+    struct AdjEnt { int32_t arc; int32_t other; int64_t cost; };   // other: the arc's second end point, bit 31 set when THIS node is the arc's target
+    std::vector<int32_t> adj_start;
+    std::vector<AdjEnt> adj;                      // arcs incident to each node, with what a re-evaluation needs next to each other
+    // every change carries the number of the search it precedes ("epoch"); a snapshot taken at epoch P knows all changes stamped <= P
+    std::vector<uint32_t> node_at, arc_at;        // epoch of the node's last potential change / the arc's last state change
+    std::vector<uint32_t> arc_stamp;              // version of the arc's key; heap entries of an older version are stale
+    std::vector<uint32_t> arc_seen;               // == cand_now: already re-evaluated for this search
+    uint32_t cand_now = 1;                        // epoch of the changes that are arriving
+    uint32_t snap_at = 0;                         // epoch the candidate list reflects
+    uint32_t heap_gap = 0;                        // latest epoch whose changes were NOT evaluated into the heap (a subtree too big to evaluate here)
     struct CandKey { int64_t c; uint32_t p; };
-    std::vector<CandKey> cand_list;               // sorted; complete below cand_thr
+    struct HeapEnt { int64_t c; uint32_t p; uint32_t stamp; };
+    std::vector<HeapEnt> heap;                    // min-heap of the current keys of the arcs touched since (lazy deletion through arc_stamp)
+    std::vector<int32_t> pivot_nodes, pivot_arcs; // touched since the last search: evaluated when the next search begins (all values final by then)
+    int64_t pivot_degree = 0;
+    bool pivot_overflow = false;
+    std::vector<int32_t> sync_nodes, sync_arcs;   // changed since the device last heard from us (values are read from the mirrors when the request is built)
+    size_t blind_count = 0;                       // the same for big subtrees: node lists taken over wholesale, with their values -- they are the
+                                                  // first blind_count entries of pend_node / pend_val already (and may have started travelling)
+    uint32_t blind_epoch = 0;                     // epoch of the first of those lists
+    int blind_sets = 0;                           // lists in there that did not come as the continuation of another one
+    bool cand_appending = false;                  // mcf_engine_append_potential is calling mcf_engine_set_potential
+    std::vector<CandKey> cand_list;               // sorted; complete below cand_thr as of snap_at
     size_t cand_ptr = 0;
     CandKey cand_thr{0, 0xFFFFFFFFu};             // p == kNone: the list holds every eligible arc
+    bool async_posted = false;                    // a refresh is on its way while the host keeps answering from the current list
+    uint32_t async_at = 0, posted_at = 0;
+    int patch_capacity = 0;                       // potential patches one request / one staged update can carry (2 * node_count + 256)
+    int cand_max_nodes = 48, cand_refresh_low = 12;
+    // where the host's time goes in candidate mode (TSC ticks; printed by mcf_engine_destroy when MCF_HIP_CAND_DEBUG is set)
+    double tk_absorb = 0, tk_decide = 0, tk_post = 0, tk_collect = 0, tk_probe = 0;
+    int64_t n_sync_posts = 0, n_async_waits = 0, n_gap_pivots = 0, n_heap_push = 0, n_heap_pop = 0, n_list_skip = 0;
     uint32_t *h_exit = nullptr, *d_exit = nullptr;
     int res_grid = 0, res_threads = kResidentThreads;
     hipEvent_t res_start = nullptr, res_stop = nullptr;
@@ -294,21 +313,12 @@ int launch_scan(mcf_engine *e, bool with_patches, bool timed)
 }
 
 // ship the pending patches with update_kernel (lists too long for the kernel arguments, or explicit flush)
-void cand_reset_dirty(mcf_engine *e);
-void cand_finish_dirty_fwd(mcf_engine *e);
+int cand_build_patches(mcf_engine *e);
 int flush_pending(mcf_engine *e)
 {
-    if (e->cand_on && (!e->dirty_nodes.empty() || !e->dirty_arcs.empty())) {
-        // candidate mode keeps its pending patches as "dirty" sets: turn them into lists (current values from the mirrors)
-        cand_finish_dirty_fwd(e);
-        e->pend_node.swap(e->dirty_nodes);
-        e->pend_val.swap(e->dirty_vals);
-        e->pend_arc.assign(e->dirty_arcs.begin(), e->dirty_arcs.end());
-        e->pend_state.resize(e->pend_arc.size());
-        for (size_t i = 0; i < e->pend_arc.size(); ++i) e->pend_state[i] = e->h_state[e->pend_arc[i]];
-        cand_reset_dirty(e);
-        e->cand_valid = false;
-    }
+    // candidate mode keeps what the device has not heard yet as lists of nodes / arcs: turn them into patches (current values from the mirrors).
+    // The list and the heap stay valid: they are bookkeeping about epochs, not about what the device knows.
+    if (e->cand_on && (!e->sync_nodes.empty() || !e->sync_arcs.empty() || e->blind_count > 0)) { const int rcb = cand_build_patches(e); if (rcb) return rcb; }
     const int n_pi_all = (int)e->pend_node.size(), n_st_all = (int)e->pend_arc.size();
     if (n_pi_all == 0 && n_st_all == 0) return MCF_OK;
     // the staging buffers hold kStageStates state patches: longer lists go out in rounds (the potentials ride in the first)
@@ -440,9 +450,45 @@ int launch_resident(mcf_engine *e, uint32_t start_seq)
     return MCF_OK;
 }
 
+// HIP multiplexes a process's streams onto a few hardware queues per device (GPU_MAX_HW_QUEUES, 4 by default) and a resident grid never
+// leaves its queue: a fifth grid on the same device could be queued behind one that only ends when its solve does.  So at most
+// kResidentSlots grids of one process run on a device at a time; an engine that finds no slot serves that search with one dispatch.
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_resident_running[kMaxDevices];
+int resident_slot_limit()
+{
+    static const int limit = [] {
+        int v = 4;
+        if (const char *q = getenv("GPU_MAX_HW_QUEUES")) { const int x = atoi(q); if (x >= 1 && x <= 64) v = x; }
+        return v;
+    }();
+    return limit;
+}
+bool resident_slot_acquire(mcf_engine *e)
+{
+    if (e->has_slot) return true;
+    std::atomic<int> &c = g_resident_running[e->d.device % kMaxDevices];
+    if (c.fetch_add(1, std::memory_order_acq_rel) >= resident_slot_limit()) { c.fetch_sub(1, std::memory_order_acq_rel); return false; }
+    e->has_slot = true;
+    return true;
+}
+void resident_slot_release(mcf_engine *e)
+{
+    if (!e->has_slot) return;
+    g_resident_running[e->d.device % kMaxDevices].fetch_sub(1, std::memory_order_acq_rel);
+    e->has_slot = false;
+}
+
 int resident_start(mcf_engine *e, uint32_t start_seq)
 {
     if (e->resident_running) return MCF_OK;
+    if (!e->has_slot) {       // given back by a stop in between (a list too long for the mailbox): the other grids leave when their solves park them
+        const double t0 = mcf::now_ns();
+        while (!resident_slot_acquire(e)) {
+            _mm_pause();
+            if (mcf::now_ns() - t0 > 20e9) return mcf::fail(MCF_ERR_TIMEOUT, "no resident slot on device %d became free within 20 s", e->d.device);
+        }
+    }
     for (int i = 0; i < 4; ++i) ((volatile uint32_t *)e->h_exit)[i] = 0;
     int rc = e->d.int_width == 32 ? launch_resident<int32_t>(e, start_seq) : launch_resident<int64_t>(e, start_seq);
     if (rc) return rc;
@@ -528,7 +574,10 @@ constexpr int kStreamMinLines = 768;           // 3840 entries per post at least
 
 void resident_stream(mcf_engine *e)
 {
-    if (!e->resident_running || e->cand_on || e->pend_arc.size() > 2 || e->in_flight != mcf_engine::kNoSearch) return;
+    // candidate mode: only one pivot's own big list travels ahead (its entries are final and repeat no node), and never beside a list refresh
+    // that is still on its way (the mailbox holds one request)
+    if (e->cand_on ? (e->async_posted || e->blind_epoch != e->cand_now || e->blind_sets > 1) : e->pend_arc.size() > 2) return;
+    if (!e->resident_running || e->in_flight != mcf_engine::kNoSearch) return;
     const int n_pi = (int)e->pend_node.size();
     const int complete = (n_pi > 1 ? n_pi - 1 : 0) / kMailboxPatchesPerLine;
     if (complete - e->stream_lines < kStreamMinLines) return;
@@ -569,6 +618,10 @@ void resident_stream(mcf_engine *e)
 }
 
 int search_end(mcf_engine *e, Key *k);
+int cand_collect(mcf_engine *e, uint32_t at);
+bool cand_records_ready(const mcf_engine *e, int g);
+int resident_stop(mcf_engine *e);
+void resident_stream(mcf_engine *e);
 
 // statistics of a resident launch that has ended (the grid wrote them into the exit record before it left)
 void resident_harvest(mcf_engine *e)
@@ -583,6 +636,10 @@ void resident_harvest(mcf_engine *e)
 int resident_stop(mcf_engine *e)
 {
     if (!e->resident_running) return MCF_OK;
+    if (e->async_posted) {       // a list refresh is on its way: take it in before the grid is told to leave
+        const int rc = cand_collect(e, e->async_at);
+        if (rc) return rc;
+    }
     if (e->in_flight == mcf_engine::kResidentSearch || e->in_flight == mcf_engine::kCandSearch) {
         // a posted search is answered before the grid is told to leave; mcf_engine_search_end then finds the answer waiting
         Key k;
@@ -599,6 +656,7 @@ int resident_stop(mcf_engine *e)
     e->resident_running = false;
     e->stream_lines = 0;
     resident_harvest(e);
+    resident_slot_release(e);
     return MCF_OK;
 }
 
@@ -669,106 +727,151 @@ int collect(mcf_engine *e, int grid, Key *out)
 
 // ------------------------------------------------------------------------------------------------ candidate cache
 // Best Eligible picks argmin (c, arc) over ALL search arcs with the CURRENT potentials (NS.cs:1644-1667).  A pivot changes the
-// potentials of one subtree and one or two states, so only arcs that touch those nodes ("dirty" arcs) change their key; every other
-// arc keeps the key the last device search saw.  That search returned a sorted candidate list that is COMPLETE below a threshold
-// (every eligible arc with a smaller key is on it).  Hence, exactly:
-//     min over clean arcs = first list entry that is still clean          (if there is one: all unlisted clean arcs lie above the threshold)
-//     min over dirty arcs = evaluated here from the host mirrors           (a handful of arcs: adjacency of the moved nodes)
-// and the entering arc is the smaller of the two.  When the list has run out and the best dirty key is not below the threshold,
-// or too many nodes are dirty, the device searches again.  The pivot sequence is the reference's, arc for arc (tests: every
-// parity test runs with the cache on and off); the device still does every full scan.
-constexpr int kCandMaxDirtyNodes = 96;          // beyond this the host evaluation costs more than a device search
-constexpr int64_t kCandMaxDirtyDegree = 1536;
-constexpr int kCandMaxDirtyArcs = 256;
+// potentials of one subtree and one or two states, so only arcs that touch those nodes change their key; every other arc keeps the key
+// the last device search saw.  A device search returns a sorted candidate list that is COMPLETE below a threshold (every eligible arc
+// with a smaller key is on it) as of the moment it was posted (its epoch).  The host keeps
+//   * the list, and for every node / arc the epoch of its last change: a list entry is CLEAN when nothing of it changed after the list's epoch;
+//   * a min-heap with the current keys of all arcs touched since (re-evaluated from the host mirrors when they are touched; at most
+//     cand_max_nodes nodes' adjacency per pivot -- a bigger subtree is not evaluated here, the device searches instead).
+// Then, exactly:   min over untouched arcs = first clean list entry (all unlisted untouched arcs lie above the threshold)
+//                  min over touched arcs   = top of the heap
+// and the entering arc is the smaller of the two -- the reference's pivot, arc for arc (every parity test runs with the cache on and off).
+// The list is refreshed ASYNCHRONOUSLY: when it runs low the next device search is posted while the host keeps answering from the current
+// list; its answer is installed when it has arrived.  The host only waits for the device when it cannot decide: after a big subtree
+// moved, or when the list ran out above the threshold.
+constexpr int64_t kCandMaxPivotDegree = 1024;   // adjacency entries re-evaluated per pivot at most
 constexpr int kCandMaxAvgDegree = 24;           // denser graphs: a single moved node already touches too many arcs
 
 inline bool cand_key_less(const mcf_engine::CandKey &a, const mcf_engine::CandKey &b) { return a.c < b.c || (a.c == b.c && a.p < b.p); }
+struct CandHeapAfter {        // std::*_heap keep the LARGEST on top: order by "comes later"
+    bool operator()(const mcf_engine::HeapEnt &a, const mcf_engine::HeapEnt &b) const { return b.c < a.c || (b.c == a.c && b.p < a.p); }
+};
 
-inline void cand_touch_node(mcf_engine *e, int u, int64_t value)
+// a potential / state change reported by the caller (the mirrors e->pi / e->h_state already hold the new value)
+inline void cand_note_node(mcf_engine *e, int u)
 {
-    if (e->node_mark[u] == e->cand_epoch) { e->dirty_vals[e->node_slot[u]] = value; return; }
-    e->node_mark[u] = e->cand_epoch;
-    e->node_slot[u] = (int32_t)e->dirty_nodes.size();
-    e->dirty_nodes.push_back(u);
-    e->dirty_vals.push_back(value);
-    if (!e->dirty_overflow) e->dirty_degree += e->adj_start[u + 1] - e->adj_start[u];
-}
-// a list the host will not evaluate anyway: just remember the patches (a repeated node is harmless, the later entry carries the later value
-// and the kernel applies entries in list order within a thread -- but two threads may race, so repeated nodes are de-duplicated at post time)
-// Long lists (or anything after one) are appended without touching the marks: the device will search next anyway.  Entries may then
-// repeat a node; cand_finish_dirty() makes all entries of a node carry the same (current) value before the list is posted.
-inline void cand_append_blind(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values)
-{
-    if (!e->dirty_overflow) { e->dirty_overflow = true; e->dirty_marked = e->dirty_nodes.size(); }
-    if (e->dirty_nodes.size() + (size_t)count > (size_t)e->patch_capacity) {
-        // repeated long lists without a search in between: squeeze the repeats out (one entry per node, current value)
-        if (++e->cand_epoch == 0) { std::fill(e->node_mark.begin(), e->node_mark.end(), 0u); std::fill(e->arc_mark.begin(), e->arc_mark.end(), 0u); e->cand_epoch = 1; for (int a : e->dirty_arcs) e->arc_mark[a] = 1; }
-        else for (int a : e->dirty_arcs) e->arc_mark[a] = e->cand_epoch;
-        size_t keep = 0;
-        for (size_t i = 0; i < e->dirty_nodes.size(); ++i) {
-            const int u = e->dirty_nodes[i];
-            if (e->node_mark[u] == e->cand_epoch) continue;
-            e->node_mark[u] = e->cand_epoch;
-            e->dirty_nodes[keep] = u;
-            e->dirty_vals[keep] = e->pi[u];
-            ++keep;
+    if (e->node_at[u] != e->cand_now) {
+        e->node_at[u] = e->cand_now;
+        e->sync_nodes.push_back(u);
+        if (!e->pivot_overflow) {
+            e->pivot_nodes.push_back(u);
+            e->pivot_degree += e->adj_start[u + 1] - e->adj_start[u];
+            if ((int)e->pivot_nodes.size() > e->cand_max_nodes || e->pivot_degree > kCandMaxPivotDegree) e->pivot_overflow = true;
         }
-        e->dirty_nodes.resize(keep);
-        e->dirty_vals.resize(keep);
-        e->dirty_marked = keep;
-        e->dirty_blind_appends = 0;
     }
-    e->dirty_nodes.insert(e->dirty_nodes.end(), nodes, nodes + count);
-    e->dirty_vals.insert(e->dirty_vals.end(), values, values + count);
-    e->dirty_blind_appends += 1;
 }
-inline void cand_finish_dirty(mcf_engine *e)
+inline void cand_note_arc(mcf_engine *e, int a)
 {
-    if (!e->dirty_overflow) return;
-    const size_t refresh = e->dirty_blind_appends > 1 ? e->dirty_nodes.size() : e->dirty_marked;
-    for (size_t i = 0; i < refresh; ++i) e->dirty_vals[i] = e->pi[e->dirty_nodes[i]];
+    if (e->arc_at[a] != e->cand_now) { e->arc_at[a] = e->cand_now; e->sync_arcs.push_back(a); e->pivot_arcs.push_back(a); }
 }
-void cand_touch_arc(mcf_engine *e, int a)
+// Long lists (a big subtree): nothing will be evaluated here -- the device searches next, and a list of its epoch or later makes the
+// touched nodes' stamps irrelevant (cand_decide) -- so the list is taken over as it is, without a look at its nodes.
+inline int cand_note_nodes_blind(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values, bool continuation)
 {
-    if (e->arc_mark[a] == e->cand_epoch) return;
-    e->arc_mark[a] = e->cand_epoch;
-    e->dirty_arcs.push_back(a);
+    e->pivot_overflow = true;
+    if (e->blind_count == 0) { e->blind_epoch = e->cand_now; e->blind_sets = 0; }
+    if (!continuation) {
+        e->blind_sets += 1;
+        // a second list may repeat nodes of the first with other values: whatever of the first has travelled is applied again, in order
+        if (e->blind_sets > 1 && e->stream_lines > 0) { const int rc = resident_stop(e); if (rc) return rc; }
+    }
+    e->pend_node.insert(e->pend_node.end(), nodes, nodes + count);
+    e->pend_val.insert(e->pend_val.end(), values, values + count);
+    e->blind_count = e->pend_node.size();
+    // a list refresh that has arrived meanwhile is taken in now, so that this list can start travelling
+    if (e->async_posted && cand_records_ready(e, 0)) { const int rc = cand_collect(e, e->async_at); if (rc) return rc; }
+    resident_stream(e);
+    return MCF_OK;
 }
-inline bool cand_arc_dirty(const mcf_engine *e, int a)
+
+inline void cand_push(mcf_engine *e, int a)
 {
-    return e->arc_mark[a] == e->cand_epoch || e->node_mark[e->h_src[a]] == e->cand_epoch || e->node_mark[e->h_tgt[a]] == e->cand_epoch;
-}
-inline void cand_eval(const mcf_engine *e, int a, mcf_engine::CandKey &best)
-{
+    if (e->arc_seen[a] == e->cand_now) return;
+    e->arc_seen[a] = e->cand_now;
+    const uint32_t stamp = ++e->arc_stamp[a];
     const int st = e->h_state[a];
     if (st == 0) return;
     const int64_t d = e->h_cost[a] + e->pi[e->h_src[a]] - e->pi[e->h_tgt[a]];
     const int64_t rc = st > 0 ? d : -d;
     if (rc >= 0) return;
-    const mcf_engine::CandKey k{rc, (uint32_t)a};
-    if (best.p == kNone || cand_key_less(k, best)) best = k;
+    e->heap.push_back(mcf_engine::HeapEnt{rc, (uint32_t)a, stamp});
+    std::push_heap(e->heap.begin(), e->heap.end(), CandHeapAfter());
 }
 
-void cand_finish_dirty_fwd(mcf_engine *e) { cand_finish_dirty(e); }
+// all changes of the pivot are in: bring the heap up to date (or note that it is not)
+void cand_absorb_pivot(mcf_engine *e)
+{
+    if (e->pivot_overflow) {
+        e->heap_gap = e->cand_now;
+        // arcs next to the moved nodes keep heap entries of older versions: they must not be taken for current ones
+        // (entries are only trusted for snapshots taken at or after heap_gap, and those know the arcs' present keys -- see cand_decide)
+    } else {
+        const int64_t *pi = e->pi.data();
+        for (int u : e->pivot_nodes) {
+            const int64_t pu = pi[u];
+            for (int i = e->adj_start[u], hi = e->adj_start[u + 1]; i < hi; ++i) {
+                const mcf_engine::AdjEnt &x = e->adj[i];
+                if (e->arc_seen[x.arc] == e->cand_now) continue;
+                e->arc_seen[x.arc] = e->cand_now;
+                const uint32_t stamp = ++e->arc_stamp[x.arc];
+                const int st = e->h_state[x.arc];
+                if (st == 0) continue;
+                const int64_t po = pi[x.other & 0x7FFFFFFF];
+                const int64_t d = x.other < 0 ? x.cost + po - pu : x.cost + pu - po;
+                const int64_t rc = st > 0 ? d : -d;
+                if (rc >= 0) continue;
+                e->heap.push_back(mcf_engine::HeapEnt{rc, (uint32_t)x.arc, stamp});
+                std::push_heap(e->heap.begin(), e->heap.end(), CandHeapAfter());
+            }
+        }
+        for (int a : e->pivot_arcs) cand_push(e, a);
+    }
+    if (e->pivot_overflow) for (int a : e->pivot_arcs) { ++e->arc_stamp[a]; }     // their old entries are stale either way
+    e->pivot_nodes.clear();
+    e->pivot_arcs.clear();
+    e->pivot_degree = 0;
+    e->pivot_overflow = false;
+    if (e->heap.size() > (1u << 18)) {          // drop what lazy deletion left behind
+        size_t keep = 0;
+        for (size_t i = 0; i < e->heap.size(); ++i)
+            if (e->heap[i].stamp == e->arc_stamp[e->heap[i].p]) e->heap[keep++] = e->heap[i];
+        e->heap.resize(keep);
+        std::make_heap(e->heap.begin(), e->heap.end(), CandHeapAfter());
+    }
+}
+
+inline bool cand_entry_clean(const mcf_engine *e, uint32_t a)
+{
+    return e->arc_at[a] <= e->snap_at && e->node_at[e->h_src[a]] <= e->snap_at && e->node_at[e->h_tgt[a]] <= e->snap_at;
+}
 
 // true: *k holds the entering arc (or "none": the scan would find nothing either) without asking the device
-bool cand_try_host(mcf_engine *e, Key *k)
+bool cand_decide(mcf_engine *e, Key *k)
 {
-    if (!e->cand_valid || e->dirty_overflow) return false;
-    if ((int)e->dirty_nodes.size() > kCandMaxDirtyNodes || e->dirty_degree > kCandMaxDirtyDegree || (int)e->dirty_arcs.size() > kCandMaxDirtyArcs) return false;
+    // the heap knows every change after snap_at only if none of them was skipped (heap_gap) -- and after a gap the entries of the arcs
+    // next to the skipped nodes are outdated without being marked so; a snapshot at or after the gap makes all of that irrelevant:
+    // an arc touched at or before snap_at is judged by the list (or lies above the threshold), whatever the heap says about it
+    if (!e->cand_valid || e->snap_at < e->heap_gap) return false;
     mcf_engine::CandKey best_d{0, kNone};
-    for (int a : e->dirty_arcs) cand_eval(e, a, best_d);
-    for (int u : e->dirty_nodes)
-        for (int i = e->adj_start[u]; i < e->adj_start[u + 1]; ++i) cand_eval(e, e->adj_arc[i], best_d);
-    while (e->cand_ptr < e->cand_list.size() && cand_arc_dirty(e, (int)e->cand_list[e->cand_ptr].p)) e->cand_ptr++;
+    while (!e->heap.empty()) {
+        const mcf_engine::HeapEnt &t = e->heap.front();
+        const uint32_t a = t.p;
+        // current version, and touched after the snapshot (an arc last touched before it is the list's business)
+        const bool fresh = t.stamp == e->arc_stamp[a];
+        const bool after = e->arc_at[a] > e->snap_at || e->node_at[e->h_src[a]] > e->snap_at || e->node_at[e->h_tgt[a]] > e->snap_at;
+        if (fresh && after) { best_d = mcf_engine::CandKey{t.c, a}; break; }
+        std::pop_heap(e->heap.begin(), e->heap.end(), CandHeapAfter());
+        e->heap.pop_back();
+    }
+    while (e->cand_ptr < e->cand_list.size() && !cand_entry_clean(e, e->cand_list[e->cand_ptr].p)) e->cand_ptr++;
     mcf_engine::CandKey win{0, kNone};
     if (e->cand_ptr < e->cand_list.size()) {
         win = e->cand_list[e->cand_ptr];
         if (best_d.p != kNone && cand_key_less(best_d, win)) win = best_d;
     } else if (e->cand_thr.p == kNone) {
-        win = best_d;                                   // the list was complete: nothing clean is left
+        win = best_d;                                   // the list was complete: nothing untouched is left
     } else if (best_d.p != kNone && cand_key_less(best_d, e->cand_thr)) {
-        win = best_d;                                   // everything clean and unlisted lies above the threshold
+        win = best_d;                                   // everything untouched and unlisted lies above the threshold
     } else {
         return false;
     }
@@ -778,22 +881,56 @@ bool cand_try_host(mcf_engine *e, Key *k)
     return true;
 }
 
-// wait for the candidate records of request `seq` and rebuild the list
-int cand_collect(mcf_engine *e, Key *out)
+// the request for a device search: every node / arc changed since the last request, with their CURRENT values
+int cand_build_patches(mcf_engine *e)
+{
+    // Every entry of a node must carry the same value (the device applies a list in no particular order).  Entries gathered here do (they
+    // are read from the mirror now); the big lists do when they are ONE pivot's list of this very epoch (its pieces repeat no node
+    // and nothing can have changed since) -- otherwise their values are read again too, and nothing of them may have travelled yet.
+    const size_t n_b = e->blind_count, n_s = e->sync_nodes.size();
+    const bool blind_current = n_b == 0 || (e->blind_epoch == e->cand_now && e->blind_sets <= 1);
+    const bool squeeze = (int64_t)n_b + (int64_t)n_s > e->patch_capacity;            // lists may repeat nodes: squeeze the repeats out
+    if ((!blind_current || squeeze) && e->stream_lines > 0) { const int rc = resident_stop(e); if (rc) return rc; }
+    if (squeeze) {
+        e->pend_node.insert(e->pend_node.end(), e->sync_nodes.begin(), e->sync_nodes.end());
+        std::sort(e->pend_node.begin(), e->pend_node.end());
+        e->pend_node.erase(std::unique(e->pend_node.begin(), e->pend_node.end()), e->pend_node.end());
+        e->pend_val.resize(e->pend_node.size());
+        for (size_t i = 0; i < e->pend_node.size(); ++i) e->pend_val[i] = e->pi[e->pend_node[i]];
+    } else {
+        if (!blind_current) for (size_t i = 0; i < n_b; ++i) e->pend_val[i] = e->pi[e->pend_node[i]];
+        e->pend_node.resize(n_b + n_s);
+        e->pend_val.resize(n_b + n_s);
+        for (size_t i = 0; i < n_s; ++i) { e->pend_node[n_b + i] = e->sync_nodes[i]; e->pend_val[n_b + i] = e->pi[e->sync_nodes[i]]; }
+    }
+    e->pend_arc.assign(e->sync_arcs.begin(), e->sync_arcs.end());
+    e->pend_state.resize(e->pend_arc.size());
+    for (size_t i = 0; i < e->pend_arc.size(); ++i) e->pend_state[i] = e->h_state[e->pend_arc[i]];
+    e->sync_nodes.clear();
+    e->sync_arcs.clear();
+    e->blind_count = 0;
+    return MCF_OK;
+}
+
+bool cand_records_ready(const mcf_engine *e, int g)
+{
+    const volatile Slot *rec = e->h_slots + (size_t)g * kCandRecords;
+    for (int r = 0; r < kCandRecords; ++r) { const int64_t c = rec[r].c; const uint32_t q = rec[r].p; if (rec[r].tag != record_tag(e->seq, c, q)) return false; }
+    return true;
+}
+
+// wait for the candidate records of request e->seq and install them as the list of epoch `at`
+int cand_collect(mcf_engine *e, uint32_t at)
 {
     const double t0 = (double)__rdtsc();
     double t0_wall = 0;
     const volatile Slot *slots = e->h_slots;
-    const uint32_t seq = e->seq;
     e->cand_list.clear();
     e->cand_thr = mcf_engine::CandKey{0, kNone};
     for (int g = 0; g < e->res_grid; ++g) {
         const volatile Slot *rec = slots + (size_t)g * kCandRecords;
         uint64_t spins = 0;
-        for (;;) {
-            bool all = true;
-            for (int r = 0; r < kCandRecords; ++r) { const int64_t c = rec[r].c; const uint32_t q = rec[r].p; all = all && rec[r].tag == record_tag(seq, c, q); }
-            if (all) break;
+        while (!cand_records_ready(e, g)) {
             _mm_pause();
             if (e->resident_running && (spins & 0xFFF) == 0xFFF && ((const volatile uint32_t *)e->h_exit)[0] != 0) {
                 int rc = resident_restart(e);
@@ -824,27 +961,43 @@ int cand_collect(mcf_engine *e, Key *out)
     std::sort(e->cand_list.begin(), e->cand_list.end(), cand_key_less);
     e->cand_ptr = 0;
     e->cand_valid = true;
-    out->r = 0;
-    if (e->cand_list.empty()) { out->c = 0; out->p = kNone; }
-    else { out->c = e->cand_list[0].c; out->p = e->cand_list[0].p; }
+    e->snap_at = at;
+    e->async_posted = false;
+    e->tk_collect += (double)__rdtsc() - t0;
     return MCF_OK;
 }
 
-// new epoch: nothing is dirty any more (the device has seen every patch)
-void cand_reset_dirty(mcf_engine *e)
+// posts a device search that carries everything the device has not heard yet; its list will be of epoch cand_now
+int cand_post(mcf_engine *e)
 {
-    e->dirty_nodes.clear();
-    e->dirty_vals.clear();
-    e->dirty_arcs.clear();
-    e->dirty_degree = 0;
-    e->dirty_overflow = false;
-    e->dirty_marked = 0;
-    e->dirty_blind_appends = 0;
-    if (++e->cand_epoch == 0) {
-        std::fill(e->node_mark.begin(), e->node_mark.end(), 0u);
-        std::fill(e->arc_mark.begin(), e->arc_mark.end(), 0u);
-        e->cand_epoch = 1;
+    if (int rcb = cand_build_patches(e)) return rcb;
+    if ((int)e->pend_arc.size() > e->mailbox_max_st) {      // hundreds of pivots' worth of state writes: cannot happen between two requests, kept for safety
+        int rc = resident_stop(e);
+        if (!rc) rc = flush_pending(e);
+        if (rc) return rc;
     }
+    e->prev_seq = e->seq;
+    e->seq += 1;
+    if (e->seq == 0) e->seq = 1;
+    int rc = resident_start(e, e->prev_seq);
+    if (rc) return rc;
+    resident_post(e, e->seq, 0u, true);
+    if (!e->pend_node.empty() || !e->pend_arc.empty()) e->st.inline_updates += 1;
+    e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
+    e->posted_at = e->cand_now;
+    e->st.arcs_scanned += e->end - e->begin;
+    return MCF_OK;
+}
+
+// forgets the list and the heap (upload, or the device state was changed behind the cache's back)
+void cand_reset(mcf_engine *e)
+{
+    e->cand_valid = false;
+    e->cand_list.clear();
+    e->cand_ptr = 0;
+    e->heap.clear();
+    e->pivot_nodes.clear(); e->pivot_arcs.clear(); e->pivot_degree = 0; e->pivot_overflow = false;
+    e->heap_gap = e->cand_now;
 }
 
 // posts / launches the search; search_end collects it.  local_search = both.
@@ -855,37 +1008,62 @@ int search_begin(mcf_engine *e)
     Key *const k = &e->answered;
     const double t0 = (double)__rdtsc();
     const bool had = !e->pend_node.empty() || !e->pend_arc.empty();
+    // a resident grid needs one of the device's slots; without one this search is served by a dispatch (the arrays are the same)
+    const bool resident_now = e->resident_ok && (e->resident_running || resident_slot_acquire(e));
     if (e->cand_on) {
-        // ---- candidate cache: answer from the host when that is provably the scan's answer
-        if (cand_try_host(e, k)) { e->st.searches += 1; e->st.host_decided += 1; e->in_flight = mcf_engine::kAnswered; return MCF_OK; }
-        // the device searches: ship every node / arc touched since its last search, with their current values
-        cand_finish_dirty(e);
-        e->pend_node.swap(e->dirty_nodes);
-        e->pend_val.swap(e->dirty_vals);
-        e->pend_arc.assign(e->dirty_arcs.begin(), e->dirty_arcs.end());
-        e->pend_state.resize(e->pend_arc.size());
-        for (size_t i = 0; i < e->pend_arc.size(); ++i) e->pend_state[i] = e->h_state[e->pend_arc[i]];
-        if ((int)e->pend_arc.size() > e->mailbox_max_st) {      // cannot happen with kCandMaxDirtyArcs, kept for safety
-            int rc = resident_stop(e);
-            if (!rc) rc = flush_pending(e);
+        const double ta = (double)__rdtsc();
+        if (e->pivot_overflow) e->n_gap_pivots += 1;
+        cand_absorb_pivot(e);
+        const double tb = (double)__rdtsc();
+        e->tk_absorb += tb - ta;
+        if (resident_now) {
+            // ---- candidate cache: answer from the host whenever that provably is the scan's answer
+            if (e->async_posted && cand_records_ready(e, 0)) { int rc = cand_collect(e, e->async_at); if (rc) return rc; }      // the refresh has arrived
+            const double tc = (double)__rdtsc();
+            e->tk_probe += tc - tb;
+            bool decided = cand_decide(e, k);
+            e->tk_decide += (double)__rdtsc() - tc;
+            if (!decided && e->async_posted) {              // the refresh is what we are waiting for
+                e->n_async_waits += 1;
+                int rc = cand_collect(e, e->async_at);
+                if (rc) return rc;
+                decided = cand_decide(e, k);
+            }
+            if (decided) {
+                e->st.searches += 1;
+                e->st.host_decided += 1;
+                e->in_flight = mcf_engine::kAnswered;
+                // running low: ask for the next list now and keep answering from this one until it is here
+                if (!e->async_posted && e->cand_thr.p != kNone && e->cand_list.size() - e->cand_ptr <= (size_t)e->cand_refresh_low) {
+                    int rc = cand_post(e);
+                    if (rc) return rc;
+                    e->async_posted = true;
+                    e->async_at = e->posted_at;
+                    e->st.async_refreshes += 1;
+                }
+                e->cand_now += 1;
+                e->launch_ticks += (double)__rdtsc() - t0;
+                return MCF_OK;
+            }
+            // the device searches: ship every node / arc touched since it last heard from us, with their current values
+            const double tp = (double)__rdtsc();
+            int rc = cand_post(e);
             if (rc) return rc;
+            e->tk_post += (double)__rdtsc() - tp;
+            e->n_sync_posts += 1;
+            e->cand_now += 1;
+            e->launch_ticks += (double)__rdtsc() - t0;
+            e->st.searches += 1;
+            e->in_flight = mcf_engine::kCandSearch;
+            return MCF_OK;
         }
-        e->prev_seq = e->seq;
-        e->seq += 1;
-        if (e->seq == 0) e->seq = 1;
-        int rc = resident_start(e, e->prev_seq);
-        if (rc) return rc;
-        resident_post(e, e->seq, 0u, true);
-        if (had || !e->pend_node.empty()) e->st.inline_updates += 1;
-        e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
-        cand_reset_dirty(e);
-        e->launch_ticks += (double)__rdtsc() - t0;
-        e->st.searches += 1;
-        e->st.arcs_scanned += e->end - e->begin;
-        e->in_flight = mcf_engine::kCandSearch;
-        return MCF_OK;
+        e->cand_now += 1;
     }
-    if (e->resident_ok) {
+    if (e->resident_ok && !resident_now) {
+        const int rcf = flush_pending(e);       // the resident grid would have received these with its request
+        if (rcf) return rcf;
+    }
+    if (resident_now) {
         // ---- resident mode: post the request into the mailbox, the grid is already running
         const bool fits = (int)e->pend_arc.size() <= e->mailbox_max_st;     // any number of potentials fits the mailbox
         if (!fits) {
@@ -938,7 +1116,15 @@ int search_end(mcf_engine *e, Key *k)
     switch (what) {
     case mcf_engine::kNoSearch: return mcf::fail(MCF_ERR_STATE, "no search in flight");
     case mcf_engine::kAnswered: *k = e->answered; return MCF_OK;
-    case mcf_engine::kCandSearch: return cand_collect(e, k);
+    case mcf_engine::kCandSearch:
+        rc = cand_collect(e, e->posted_at);
+        if (rc) return rc;
+        // the device saw everything up to this search, so its best key IS the answer (the global minimum is some workgroup's best and lies
+        // below every unreported key); changes reported since search_begin belong to the next search and are not looked at
+        k->r = 0;
+        if (e->cand_list.empty()) { k->c = 0; k->p = kNone; }
+        else { k->c = e->cand_list[0].c; k->p = e->cand_list[0].p; }
+        return MCF_OK;
     case mcf_engine::kResidentSearch: return collect(e, e->res_grid, k);
     case mcf_engine::kDispatchSearch:
         rc = collect(e, e->grid, k);
@@ -1168,7 +1354,8 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
                 for (size_t l = 0; l < (size_t)kMailboxTail / 16 + e->mailbox_lines; ++l) mailbox_write_line(e->mailbox + 16 * l, zero);
                 _mm_sfence();
                 e->resident_ok = true;
-                e->cand_on = (desc->flags & MCF_ENGINE_CANDIDATES) && whole && e->resident_reg && desc->rule == MCF_RULE_BEST_ELIGIBLE &&
+                e->cand_on = !(desc->flags & MCF_ENGINE_NO_CANDIDATES) && !(getenv("MCF_HIP_CANDIDATES") && getenv("MCF_HIP_CANDIDATES")[0] == '0') &&
+                             whole && e->resident_reg && desc->rule == MCF_RULE_BEST_ELIGIBLE &&
                              2 * (int64_t)desc->search_arc_num <= (int64_t)kCandMaxAvgDegree * desc->node_count;
             }
         }
@@ -1195,6 +1382,14 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
 void mcf_engine_destroy(mcf_engine *e)
 {
     if (!e) return;
+    if (e->cand_on && getenv("MCF_HIP_CAND_DEBUG") && e->st.searches > 1000) {
+        const double ns_per_tick = (mcf::now_ns() - e->cal_ns) / std::max(1.0, (double)__rdtsc() - e->cal_ticks);
+        const double n = (double)e->st.searches;
+        fprintf(stderr, "[cand] searches %lld host %lld async %lld sync_posts %lld async_waits %lld gap_pivots %lld | per search ns: absorb %.0f probe %.0f decide %.0f post %.0f collect %.0f wait %.0f | heap size %zu\n",
+                (long long)e->st.searches, (long long)e->st.host_decided, (long long)e->st.async_refreshes, (long long)e->n_sync_posts, (long long)e->n_async_waits,
+                (long long)e->n_gap_pivots, e->tk_absorb * ns_per_tick / n, e->tk_probe * ns_per_tick / n, e->tk_decide * ns_per_tick / n, e->tk_post * ns_per_tick / n,
+                e->tk_collect * ns_per_tick / n, e->wait_ticks * ns_per_tick / n, e->heap.size());
+    }
     (void)hipSetDevice(e->d.device);
     if (e->resident_running) (void)resident_stop(e);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -1290,18 +1485,25 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
         e->adj_start.assign(n + 1, 0);
         for (int a = 0; a < m_s; ++a) { e->adj_start[source[a] + 1]++; if (target[a] != source[a]) e->adj_start[target[a] + 1]++; }
         for (int u = 0; u < n; ++u) e->adj_start[u + 1] += e->adj_start[u];
-        e->adj_arc.assign(e->adj_start[n], 0);
+        e->adj.assign(e->adj_start[n], mcf_engine::AdjEnt{0, 0, 0});
         std::vector<int32_t> fill(e->adj_start.begin(), e->adj_start.end() - 1);
-        for (int a = 0; a < m_s; ++a) { e->adj_arc[fill[source[a]]++] = a; if (target[a] != source[a]) e->adj_arc[fill[target[a]]++] = a; }
-        e->node_mark.assign(n, 0u);
-        e->node_slot.assign(n, 0);
-        e->dirty_vals.clear();
-        e->dirty_overflow = false;
-        e->arc_mark.assign(m_s, 0u);
-        e->cand_epoch = 1;
-        e->dirty_nodes.clear(); e->dirty_arcs.clear(); e->dirty_degree = 0;
-        e->cand_valid = false;
-        e->cand_list.clear();
+        for (int a = 0; a < m_s; ++a) {
+            e->adj[fill[source[a]]++] = mcf_engine::AdjEnt{a, target[a], cost[a]};
+            if (target[a] != source[a]) e->adj[fill[target[a]]++] = mcf_engine::AdjEnt{a, (int32_t)((uint32_t)source[a] | 0x80000000u), cost[a]};
+        }
+        e->node_at.assign(n, 0u);
+        e->arc_at.assign(m_s, 0u);
+        e->arc_stamp.assign(m_s, 0u);
+        e->arc_seen.assign(m_s, 0u);
+        e->cand_now = 1;
+        e->snap_at = 0;
+        e->heap_gap = 0;
+        e->async_posted = false;
+        e->sync_nodes.clear(); e->sync_arcs.clear(); e->blind_count = 0;
+        cand_reset(e);
+        e->heap_gap = 0;
+        if (const char *u = getenv("MCF_HIP_CAND_NODES")) { const int v = atoi(u); if (v >= 0 && v <= 4096) e->cand_max_nodes = v; }
+        if (const char *u = getenv("MCF_HIP_CAND_REFRESH")) { const int v = atoi(u); if (v >= 0 && v <= 4096) e->cand_refresh_low = v; }
     }
     e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
     e->next_arc = 0;
@@ -1316,7 +1518,7 @@ int mcf_engine_patch_state(mcf_engine *e, int32_t count, const int32_t *arcs, co
         if (arcs[i] < 0 || arcs[i] >= e->d.arc_capacity) return mcf::fail(MCF_ERR_INVALID, "arc %d out of range", arcs[i]);
         if (states[i] < -1 || states[i] > 1) return mcf::fail(MCF_ERR_INVALID, "state %d is not -1/0/1", states[i]);
         if (arcs[i] < e->begin || arcs[i] >= e->end) continue;   // not resident here (outside the search range or another shard)
-        if (e->cand_on) { e->h_state[arcs[i]] = states[i]; cand_touch_arc(e, arcs[i]); continue; }
+        if (e->cand_on) { e->h_state[arcs[i]] = states[i]; cand_note_arc(e, arcs[i]); continue; }
         // the device addresses state[] by position: begin + position of the arc in the stored order
         if (e->bucket_nodes > 0 && e->pos_of.empty()) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
         const int32_t where = e->bucket_nodes > 0 ? e->begin + e->pos_of[arcs[i] - e->begin] : arcs[i];
@@ -1349,14 +1551,13 @@ int mcf_engine_update_potential(mcf_engine *e, int32_t count, const int32_t *nod
             if ((unsigned)nodes[i] >= (unsigned)e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "node %d out of range", nodes[i]);
             if (e->d.int_width == 32 && !fits32(e->pi[nodes[i]] + sigma)) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d leaves int32; create the engine with int_width 64", nodes[i]);
         }
-        if (count > kCandMaxDirtyNodes || e->dirty_overflow) {
-            std::vector<int64_t> &tmp = e->pend_val;      // scratch: empty in candidate mode between searches
-            tmp.resize(count);
-            for (int i = 0; i < count; ++i) tmp[i] = (e->pi[nodes[i]] += sigma);
-            cand_append_blind(e, count, nodes, tmp.data());
-            tmp.clear();
+        if (count > e->cand_max_nodes || e->pivot_overflow) {
+            std::vector<int64_t> vals((size_t)count);
+            for (int i = 0; i < count; ++i) vals[i] = (e->pi[nodes[i]] += sigma);
+            const int rcn = cand_note_nodes_blind(e, count, nodes, vals.data(), false);
+            if (rcn) return rcn;
         } else {
-            for (int i = 0; i < count; ++i) { const int64_t v = (e->pi[nodes[i]] += sigma); cand_touch_node(e, nodes[i], v); }
+            for (int i = 0; i < count; ++i) { e->pi[nodes[i]] += sigma; cand_note_node(e, nodes[i]); }
         }
         e->st.potential_nodes += count;
         return MCF_OK;
@@ -1391,12 +1592,9 @@ int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes,
         if (narrow && !fits32(values[i])) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d leaves int32; create the engine with int_width 64", nodes[i]);
     }
     if (e->cand_on) {                 // the mirror stays authoritative in candidate mode
-        if (count > kCandMaxDirtyNodes || e->dirty_overflow) {
-            for (int i = 0; i < count; ++i) e->pi[nodes[i]] = values[i];
-            cand_append_blind(e, count, nodes, values);
-        } else {
-            for (int i = 0; i < count; ++i) { e->pi[nodes[i]] = values[i]; cand_touch_node(e, nodes[i], values[i]); }
-        }
+        for (int i = 0; i < count; ++i) e->pi[nodes[i]] = values[i];
+        if (count > e->cand_max_nodes || e->pivot_overflow) { const int rcn = cand_note_nodes_blind(e, count, nodes, values, e->cand_appending); if (rcn) return rcn; }
+        else for (int i = 0; i < count; ++i) cand_note_node(e, nodes[i]);
         e->st.potential_nodes += count;
         return MCF_OK;
     }
@@ -1414,7 +1612,13 @@ int mcf_engine_append_potential(mcf_engine *e, int32_t count, const int32_t *nod
     if (!e || count < 0 || (count && (!nodes || !values))) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_append_potential: bad arguments");
     if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
     if (count == 0) return MCF_OK;
-    if (e->cand_on || e->pend_node.empty()) return mcf_engine_set_potential(e, count, nodes, values);     // nothing queued yet / candidate mode takes any number of calls
+    if (e->cand_on) {              // candidate mode takes any number of calls; a piece that continues this pivot's list repeats none of its nodes
+        e->cand_appending = e->pivot_overflow && e->blind_count > 0 && e->blind_epoch == e->cand_now;
+        const int rc = mcf_engine_set_potential(e, count, nodes, values);
+        e->cand_appending = false;
+        return rc;
+    }
+    if (e->pend_node.empty()) return mcf_engine_set_potential(e, count, nodes, values);     // nothing queued yet
     if ((int64_t)e->pend_node.size() + count > e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "more nodes appended than the graph has: the lists of one pivot must not repeat nodes");
     const bool narrow = e->d.int_width == 32;
     for (int i = 0; i < count; ++i) {

@@ -736,6 +736,7 @@ int mcf_ns_prepare(mcf_ns *s)
             if (sharing > 1) {                       // shards rehearsed on one GPU: every grid must fit beside the others
                 dr.flags |= MCF_ENGINE_SHARE_DEVICE;
                 dr.resident_workgroups = std::max(1, 256 / sharing);
+                if (sharing > 3) dr.flags |= MCF_ENGINE_DISPATCH;      // more grids than the device has hardware queues for this process (engine.hip: resident slots)
             }
         }
         mcf_engine *e = nullptr;

@@ -32,8 +32,11 @@ def _oracle_scan(rule, optimized, a, m_s, block, next_arc):
     return O.scan_block(m_s, a["state"], a["cost"], a["src"], a["tgt"], a["pi"], block, optimized, next_arc)
 
 
-MODES = [pytest.param(0, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"), pytest.param(M.ENGINE_CANDIDATES, id="candidates"),
-         pytest.param(M.ENGINE_SHARE_DEVICE, id="resident-shared")]      # resident grid without register-resident potentials
+# default = resident grid, with the candidate cache where it applies (Best Eligible, register-resident arcs, sparse graph)
+MODES = [pytest.param(M.ENGINE_NO_CANDIDATES, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"), pytest.param(0, id="candidates"),
+         pytest.param(M.ENGINE_SHARE_DEVICE | M.ENGINE_NO_CANDIDATES, id="resident-shared"),      # resident grid without register-resident potentials
+         pytest.param(M.ENGINE_SHARE_DEVICE, id="candidates-shared")]
+CAND_MODES = (0, M.ENGINE_SHARE_DEVICE)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -82,9 +85,11 @@ def test_scan_matches_oracle_on_random_arrays(width, rule, optimized, mode):
         assert np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
         st = eng.stats()
         assert st["searches"] == 12 and st["resident"] == (0 if mode == M.ENGINE_DISPATCH else 1)
+        if mode not in CAND_MODES:
+            assert st["candidates"] == 0
         if mode == M.ENGINE_DISPATCH:
             assert (st["inline_updates"] > 0 and st["update_launches"] > 0) or n < 97
-        elif mode == M.ENGINE_CANDIDATES and rule == O.RULE_BEST and m_s <= 1 << 20 and 2 * m_s <= 24 * n:
+        elif mode in CAND_MODES and rule == O.RULE_BEST and m_s <= 1 << 20 and 2 * m_s <= 24 * n:
             assert st["candidates"] == 1 and st["resident_requests"] + st["host_decided"] >= 12
         else:
             assert st["resident_requests"] >= 12 and st["update_launches"] <= 1    # the patches queued after the last search
@@ -159,7 +164,8 @@ def test_solve_is_pivot_for_pivot_identical(name, mode):
         assert ns.get_total_cost() == o.total_cost
         assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
         m = ns.get_metrics()
-        assert m["iterations"] == o.n_pivots and m["block_size"] == o.initial_block_size and m["search_arc_num"] == o.search_arc_num
+        assert m["iterations"] == o.n_pivots and m["search_arc_num"] == o.search_arc_num
+        assert rule != O.RULE_BLOCK or m["block_size"] == o.initial_block_size
         # the rest of SolverMetrics (OptimizationTypes.cs:53-59): only the plain BlockSearchPivot counts arcs and reports block sizes
         assert m["total_arcs_checked"] == o.arcs_checked and m["config_flags"] == (o.config_flags if sem == O.SEM_CSHARP else m["config_flags"])
         if sem == O.SEM_CSHARP and rule == O.RULE_BLOCK:
@@ -168,7 +174,7 @@ def test_solve_is_pivot_for_pivot_identical(name, mode):
         else:
             assert (m["initial_block_size"], m["final_block_size"], m["total_arcs_checked"]) == (0, 0, 0)
         assert m["engine"]["resident"] == (0 if mode == M.ENGINE_DISPATCH else 1)
-        if mode == M.ENGINE_CANDIDATES and rule == O.RULE_BEST and 2 * o.search_arc_num <= 24 * (p.n + 1):
+        if mode in CAND_MODES and rule == O.RULE_BEST and 2 * o.search_arc_num <= 24 * (p.n + 1):
             assert m["engine"]["candidates"] == 1 and m["engine"]["host_decided"] + m["engine"]["resident_requests"] >= o.n_pivots
 
 
@@ -353,7 +359,7 @@ def test_candidate_cache_answers_most_searches_and_changes_nothing():
     device request."""
     g = M.netgen_like(13502460, 20_000, 70_000, 140, 140)
     p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
-    o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, O.RULE_BEST, flags=M.ENGINE_CANDIDATES)
+    o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, O.RULE_BEST, flags=0)
     assert st == st_o == 1 and np.array_equal(ns.trace(), tr_o)
     assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
     e = ns.get_metrics()["engine"]
@@ -362,7 +368,7 @@ def test_candidate_cache_answers_most_searches_and_changes_nothing():
     rng = np.random.default_rng(11)
     m_s, n = 50_000, 9_000
     a = _random_soa(rng, m_s, n, 40, 400, extra=0)
-    eng = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible, flags=M.ENGINE_CANDIDATES)
+    eng = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible, flags=0)
     eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
     for it in range(300):
         f, e_, c = eng.find_entering()
@@ -452,7 +458,7 @@ def test_random_small_networks_all_outcomes(seed):
         p = _random_problem(rng, n, m, kind)
         stype = O.LEQ if trial % 4 == 3 else O.GEQ
         sem, rule = [(O.SEM_CSHARP_OPT, O.RULE_BLOCK), (O.SEM_CSHARP, O.RULE_BEST), (O.SEM_CSHARP_OPT, O.RULE_FIRST), (O.SEM_CSHARP, O.RULE_BLOCK)][trial % 4]
-        flags = [0, M.ENGINE_DISPATCH, M.ENGINE_CANDIDATES][trial % 3]
+        flags = [M.ENGINE_NO_CANDIDATES, M.ENGINE_DISPATCH, 0][trial % 3]
         o, st_o, tr_o, ns, st = _solve_both(p, sem, rule, supply_type=stype, flags=flags)
         assert st == st_o, (seed, trial, st, st_o)
         assert np.array_equal(ns.trace(), tr_o[: len(ns.trace())])
@@ -542,13 +548,14 @@ def test_register_resident_potentials_pivot_for_pivot():
     points' potentials in registers and sees every kind of patch list (one node ... more than 4096) in real proportions."""
     g = M.netgen_like(7, 20_000, 60_000, 100, 100)
     p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
-    for rule in (O.RULE_BEST, O.RULE_BLOCK):
-        o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, rule)
+    for rule, flags in ((O.RULE_BEST, M.ENGINE_NO_CANDIDATES), (O.RULE_BLOCK, 0), (O.RULE_BEST, 0)):
+        o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, rule, flags=flags)
         assert st == st_o == O.OPTIMAL
         assert np.array_equal(ns.trace(), tr_o), int(np.argmax(ns.trace()[: len(tr_o)] != tr_o[: len(ns.trace())]))
         assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
         m = ns.get_metrics()
         assert m["engine"]["resident"] == 1 and m["engine"]["scan_threads"] <= 512
+        assert m["engine"]["candidates"] == (1 if rule == O.RULE_BEST and flags == 0 else 0)
 
 
 @pytest.mark.gpu
@@ -613,7 +620,8 @@ def test_search_in_two_halves(mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [pytest.param(0, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"), pytest.param(M.ENGINE_SHARE_DEVICE, id="resident-shared")])
+@pytest.mark.parametrize("mode", [pytest.param(M.ENGINE_NO_CANDIDATES, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"),
+                                  pytest.param(M.ENGINE_SHARE_DEVICE | M.ENGINE_NO_CANDIDATES, id="resident-shared"), pytest.param(0, id="candidates")])
 @pytest.mark.parametrize("m_s,n", [(400003, 100001), (60001, 16000)])
 def test_state_patch_lists_of_any_length(mode, m_s, n):
     """mcf_engine_patch_state with 65, 200 and 5000 distinct arcs between two searches, each time with a potential list pending
