@@ -188,17 +188,26 @@ def microbench():
     rng = np.random.default_rng(7)
     out = []
 
-    def run(label, n_nodes, m_s, src, tgt, cost, state, pi, endpoints):
+    def run(label, n_nodes, m_s, src, tgt, cost, state, pi, endpoints, env=None):
+        for k, v in (env or {}).items():
+            os.environ[k] = str(v)
         eng = M.PivotEngine(n_nodes, m_s, m_s, rule=M.PivotRule.BestEligible, int_width=64, flags=M.ENGINE_DISPATCH)
+        for k in (env or {}):
+            os.environ.pop(k, None)
         eng.upload(src, tgt, cost, state, pi)
         st = eng.stats()
-        nbytes = st["bytes_per_scan"]
+        survey = st["bytes_per_scan"]              # 17 B per arc + the potentials once
+        nbytes = st["scan_bytes_read"]             # what this layout's scan has to read (9 B per arc in the RC layout: no potential gathers)
         warm = eng.bench_scan(reps=20)
         cold = eng.bench_scan(reps=8, cold=True, flush_bytes=512 << 20)
-        out.append({"case": label, "arcs": m_s, "nodes": n_nodes, "dtype": "i64", "endpoints": endpoints, "bytes": nbytes,
+        out.append({"case": label, "arcs": m_s, "nodes": n_nodes, "dtype": "i64", "endpoints": endpoints,
+                    "layout": "reduced costs kept per arc (RC): state + reduced cost streamed, nothing gathered" if st["rc_layout"] else
+                              ("potentials in LDS" if n_nodes <= 16384 else "SoA arcs + two potential gathers per arc"),
+                    "bytes": nbytes, "survey_bytes": survey,
                     "grid": f"{st['scan_workgroups']}x{st['scan_threads']}", "potentials_in_lds": n_nodes <= 16384,
                     "warm_us": warm[0] / 1e3, "cold_us": cold[0] / 1e3, "warm_GBs": nbytes / warm[0], "cold_GBs": nbytes / cold[0],
-                    "warm_frac_of_hbm_peak": nbytes / warm[0] / HBM_PEAK_GBS, "cold_frac_of_hbm_peak": nbytes / cold[0] / HBM_PEAK_GBS})
+                    "warm_frac_of_hbm_peak": nbytes / warm[0] / HBM_PEAK_GBS, "cold_frac_of_hbm_peak": nbytes / cold[0] / HBM_PEAK_GBS,
+                    "cold_GBs_in_survey_bytes": survey / cold[0]})
 
     # SURVEY.md 8d sizes: m_s in {4e5, 1e6, 8e6, 6.4e7}, uniform random arrays
     for label, m_s, n in (("config-3 size, uniform random end points", 400_000, 100_001),
@@ -217,12 +226,14 @@ def microbench():
     ms = it["search_arc_num"]
     run("NETGEN-like 1M nodes / 8M arcs start basis (config 5 arrays)", g5.node_count + 1, ms, it["source"][:ms], it["target"][:ms],
         it["cost"][:ms], it["state"][:ms], it["pi"], "generator order: grouped by tail, random heads")
+    run("the same arrays with the gathering scan (bucketed layout, round 1)", g5.node_count + 1, ms, it["source"][:ms], it["target"][:ms],
+        it["cost"][:ms], it["state"][:ms], it["pi"], "generator order: grouped by tail, random heads", env={"MCF_HIP_RC": 0})
     return out
 
 
 def large_instance_sample(M, local_rank, with_cpu, gpu_pivots=3000, cpu_seconds=4.0):
     """BASELINE.json configs[4] on ONE GPU: the first pivots of NETGEN-like 1M nodes / 8M arcs, Best Eligible (9M search arcs per scan,
-    bucketed layout, one dispatch per search).  Same-rule CPU port on the same first pivots beside it."""
+    RC layout, one dispatch per search).  Same-rule CPU port on the same first pivots beside it."""
     g5 = M.netgen_like(SEED, 1_000_000, 8_000_000, 1000, 1000)
     ns = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True)
     ns.set_device(local_rank, 64, 0, 0).set_pivot_limit(gpu_pivots).prepare()
@@ -231,7 +242,9 @@ def large_instance_sample(M, local_rank, with_cpu, gpu_pivots=3000, cpu_seconds=
     out = {"workload": "NETGEN-like 1M nodes / 8M arcs (config 5 on one GPU), Best Eligible, int64, first pivots only", "pivots": m["iterations"],
            "us_per_pivot": m["loop_us"] / it, "pivot_search_us": m["pivot_search_us"] / it, "pivots_per_s": it / (m["loop_us"] / 1e6),
            "engine_mode": "resident grid" if m["engine"]["resident"] else "one dispatch per search",
-           "search_arcs": m["search_arc_num"], "scan_GBps_incl_round_trip": m["engine"]["bytes_per_scan"] / (m["pivot_search_us"] / it) / 1e3}
+           "layout": "reduced costs kept per arc (RC)" if m["engine"]["rc_layout"] else "SoA arcs + potential gathers",
+           "search_arcs": m["search_arc_num"], "bytes_read_per_scan": m["engine"]["scan_bytes_read"],
+           "scan_GBps_incl_round_trip": m["engine"]["scan_bytes_read"] / (m["pivot_search_us"] / it) / 1e3}
     del ns
     if with_cpu:
         b = cpu_baseline(g5, M.PivotRule.BestEligible, cpu_seconds)

@@ -173,6 +173,10 @@ MCF_API int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t
  * In resident mode the complete lines start travelling to the device at once and the grid applies them while the host is still
  * walking; the next search finishes the list. */
 MCF_API int mcf_engine_append_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values);
+/* append_potential with the caller's promise that every values[i] is its node's previous potential + sigma -- which is what
+ * UpdatePotentials produces: one sigma per pivot (NS.cs:1187-1190).  Layouts that keep reduced costs per arc (large sparse instances)
+ * then shift those by sigma directly, for short lists inside the next search's dispatch. */
+MCF_API int mcf_engine_shift_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values, int64_t sigma);
 
 /* Rewrites (source, target, cost) of arcs, e.g. artificial arcs re-pointed by a warm start. Synchronous. */
 MCF_API int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, const int32_t *source,
@@ -250,6 +254,9 @@ typedef struct mcf_engine_stats {
     int32_t comm_ranks;           /* ranks of the RCCL communicator as ncclCommCount reports them (0: no communicator) */
     int32_t reserved;
     int64_t async_refreshes;      /* candidate lists requested ahead of need (the host kept answering while the device searched) */
+    int64_t scan_bytes_read;      /* bytes one scan of THIS engine's layout has to read: bytes_per_scan for the gathering layouts, 9 per arc
+                                     (state + the arc's reduced cost) in the RC layout, where the gathers moved into the potential update */
+    int64_t rc_layout;            /* 1: reduced costs are kept per arc (large sparse instances) */
 } mcf_engine_stats;
 MCF_API int mcf_engine_get_stats(mcf_engine *e, mcf_engine_stats *out);
 MCF_API int mcf_engine_reset_stats(mcf_engine *e);

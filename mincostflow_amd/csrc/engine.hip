@@ -104,6 +104,14 @@ struct mcf_engine {
     int bucket_nodes = 0;          // nodes per range; 0 = arcs are stored in their own order
     std::vector<int32_t> pos_of;   // local arc -> local position (identity when bucket_nodes == 0: empty)
     int32_t *d_orig = nullptr;     // local position -> global arc id
+    // RC layout (kernels.hip.h): reduced costs kept per arc, maintained by scatter from the moved nodes; the scan gathers nothing
+    bool rc_mode = false;
+    int64_t *d_rc = nullptr;
+    int32_t *d_adj_start = nullptr;
+    uint32_t *d_adj = nullptr;     // the shard's arcs at each node: local position, bit 31 = the node is the arc's target
+    std::vector<int32_t> h_adj_start;   // host copy of d_adj_start (short lists name their arc lists in the scan's arguments)
+    bool pend_shift = false;       // every pending potential is its node's previous value + pend_sigma (mcf_engine_shift_potential)
+    int64_t pend_sigma = 0;
     bool no_pireg = false;         // MCF_ENGINE_SHARE_DEVICE or MCF_HIP_PIREG=0: the resident grid gathers the potentials for every request
     int lds_grid = 0;
     uint32_t seq = 0;
@@ -312,6 +320,127 @@ int launch_scan(mcf_engine *e, bool with_patches, bool timed)
     return MCF_OK;
 }
 
+void fill_rc_params(mcf_engine *e, RcParams &p, bool with_states)
+{
+    p.state_ro = e->d_state; p.state = e->d_state; p.rc = e->d_rc; p.slots = e->d_slots;
+    p.base = e->begin; p.count_padded = e->count_padded; p.m_s = e->d.search_arc_num;
+    p.next_arc = e->next_arc >= e->d.search_arc_num ? 0 : e->next_arc;
+    p.block_size = e->block_size;
+    p.rstar = -1;
+    if (e->d.rule == MCF_RULE_BLOCK_SEARCH && e->d.semantics == MCF_SEM_OPTIMIZED && e->next_arc < e->d.search_arc_num) {
+        const int len1 = e->d.search_arc_num - e->next_arc;   // BSPO.cs:49 first range
+        if (len1 % e->block_size != 0) p.rstar = len1 / e->block_size;
+    }
+    p.seq = e->seq;
+    p.n_st = 0;
+    p.n_pi = 0;
+    p.sigma = 0;
+    p.pi = e->d_pi;
+    p.adj = e->d_adj;
+    p.narrow = e->d.int_width == 32 ? 1 : 0;
+    if (with_states) {
+        p.n_st = (int)e->pend_arc.size();
+        for (int i = 0; i < p.n_st; ++i) { p.st_arc[i] = e->pend_arc[i]; p.st_val[i] = e->pend_state[i]; }
+        p.n_pi = (int)e->pend_node.size();           // rc_inline_ok has checked the list
+        p.sigma = e->pend_sigma;
+        p.prefix[0] = 0;
+        for (int i = 0; i < p.n_pi; ++i) {
+            const int u = e->pend_node[i];
+            p.pi_node[i] = u;
+            p.adj_lo[i] = e->h_adj_start[u];
+            p.prefix[i + 1] = p.prefix[i] + (e->h_adj_start[u + 1] - e->h_adj_start[u]);
+        }
+    }
+}
+
+// a pending potential list short enough to ride in the scan's arguments (RC layout): one common shift, few nodes, short arc lists
+bool rc_inline_ok(const mcf_engine *e)
+{
+    const size_t n = e->pend_node.size();
+    if (n == 0) return true;
+    if (!e->pend_shift || n > (size_t)kRcInlineNodes) return false;
+    int64_t entries = 0;
+    for (size_t i = 0; i < n; ++i) entries += e->h_adj_start[e->pend_node[i] + 1] - e->h_adj_start[e->pend_node[i]];
+    return entries <= kRcInlineEntries;
+}
+
+template <int RULE, bool OPT>
+void launch_rc_u(mcf_engine *e, const RcParams &p, hipEvent_t start, hipEvent_t stop)
+{
+    const dim3 grid(e->grid), block(kThreads);
+    if (e->unroll == 4) {
+        if (start) hipExtLaunchKernelGGL((scan_rc_kernel<RULE, OPT, 4>), grid, block, 0, e->stream, start, stop, 0, p);
+        else hipLaunchKernelGGL((scan_rc_kernel<RULE, OPT, 4>), grid, block, 0, e->stream, p);
+    } else if (e->unroll == 2) {
+        if (start) hipExtLaunchKernelGGL((scan_rc_kernel<RULE, OPT, 2>), grid, block, 0, e->stream, start, stop, 0, p);
+        else hipLaunchKernelGGL((scan_rc_kernel<RULE, OPT, 2>), grid, block, 0, e->stream, p);
+    } else {
+        if (start) hipExtLaunchKernelGGL((scan_rc_kernel<RULE, OPT, 1>), grid, block, 0, e->stream, start, stop, 0, p);
+        else hipLaunchKernelGGL((scan_rc_kernel<RULE, OPT, 1>), grid, block, 0, e->stream, p);
+    }
+}
+
+void dispatch_scan_rc(mcf_engine *e, const RcParams &p, hipEvent_t start, hipEvent_t stop)
+{
+    switch (e->d.rule) {
+    case MCF_RULE_BEST_ELIGIBLE: launch_rc_u<MCF_RULE_BEST_ELIGIBLE, false>(e, p, start, stop); break;
+    case MCF_RULE_FIRST_ELIGIBLE: launch_rc_u<MCF_RULE_FIRST_ELIGIBLE, false>(e, p, start, stop); break;
+    default:
+        if (e->d.semantics == MCF_SEM_OPTIMIZED) launch_rc_u<MCF_RULE_BLOCK_SEARCH, true>(e, p, start, stop);
+        else launch_rc_u<MCF_RULE_BLOCK_SEARCH, false>(e, p, start, stop);
+    }
+}
+
+int launch_scan_rc(mcf_engine *e, bool with_states, bool timed)
+{
+    RcParams p;
+    fill_rc_params(e, p, with_states);
+    hipEvent_t start = nullptr, stop = nullptr;
+    if (timed) {
+        if (e->ev_head - e->ev_tail >= mcf_engine::kEvRing) { int rc = drain_events(e, true); if (rc) return rc; }
+        const int i = e->ev_head % mcf_engine::kEvRing;
+        start = e->ev_start[i];
+        stop = e->ev_stop[i];
+        e->ev_head++;
+    }
+    dispatch_scan_rc(e, p, start, stop);
+    HIP_TRY(hipGetLastError());
+    e->st.scan_launches += 1;
+    e->st.arcs_scanned += e->end - e->begin;
+    return MCF_OK;
+}
+
+// (re)computes the per-arc reduced costs of the RC layout from the arrays on the device
+int rc_recompute(mcf_engine *e)
+{
+    const int blocks = e->count_padded / kThreads;
+    if (e->d.int_width == 32)
+        hipLaunchKernelGGL(rc_init_kernel<int32_t>, dim3(blocks), dim3(kThreads), 0, e->stream, e->d_src, e->d_tgt, (const int32_t *)e->d_cost, (const int32_t *)e->d_pi, e->d_rc, e->count_padded);
+    else
+        hipLaunchKernelGGL(rc_init_kernel<int64_t>, dim3(blocks), dim3(kThreads), 0, e->stream, e->d_src, e->d_tgt, (const int64_t *)e->d_cost, (const int64_t *)e->d_pi, e->d_rc, e->count_padded);
+    HIP_TRY(hipGetLastError());
+    return MCF_OK;
+}
+
+// the shard's arcs at each node (RC layout): counting sort of the local positions by end point
+int rc_build_adjacency(mcf_engine *e, const int32_t *src_local, const int32_t *tgt_local)
+{
+    const int n = e->d.node_count, count = e->end - e->begin;
+    std::vector<int32_t> start((size_t)n + 1, 0);
+    for (int i = 0; i < count; ++i) { start[src_local[i] + 1]++; start[tgt_local[i] + 1]++; }
+    for (int u = 0; u < n; ++u) start[u + 1] += start[u];
+    std::vector<uint32_t> adj((size_t)std::max(1, 2 * count), 0u);
+    std::vector<int32_t> fill(start.begin(), start.end() - 1);
+    for (int i = 0; i < count; ++i) {
+        adj[fill[src_local[i]]++] = (uint32_t)i;
+        adj[fill[tgt_local[i]]++] = (uint32_t)i | 0x80000000u;
+    }
+    HIP_TRY(hipMemcpy(e->d_adj_start, start.data(), sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    e->h_adj_start = start;
+    HIP_TRY(hipMemcpy(e->d_adj, adj.data(), sizeof(uint32_t) * adj.size(), hipMemcpyHostToDevice));
+    return MCF_OK;
+}
+
 // ship the pending patches with update_kernel (lists too long for the kernel arguments, or explicit flush)
 int cand_build_patches(mcf_engine *e);
 int flush_pending(mcf_engine *e)
@@ -330,7 +459,13 @@ int flush_pending(mcf_engine *e)
         if (n_pi) { memcpy(s.nodes, e->pend_node.data(), sizeof(int32_t) * n_pi); memcpy(s.values, e->pend_val.data(), sizeof(int64_t) * n_pi); }
         if (n_st) { memcpy(s.arcs, e->pend_arc.data() + st0, sizeof(int32_t) * n_st); memcpy(s.states, e->pend_state.data() + st0, sizeof(int32_t) * n_st); }
         const int blocks = (std::max(n_pi, n_st) + kThreads - 1) / kThreads;
-        if (e->d.int_width == 32)
+        if (e->rc_mode && e->d.int_width == 32)
+            hipLaunchKernelGGL(update_rc_kernel<int32_t>, dim3(blocks), dim3(kThreads), 0, e->stream, (int32_t *)e->d_pi, (const int32_t *)s.d_nodes, (const int64_t *)s.d_values, n_pi,
+                               e->d_state, (const int32_t *)s.d_arcs, (const int32_t *)s.d_states, n_st, e->begin, e->count_padded, e->d_rc, e->d_adj_start, e->d_adj);
+        else if (e->rc_mode)
+            hipLaunchKernelGGL(update_rc_kernel<int64_t>, dim3(blocks), dim3(kThreads), 0, e->stream, (int64_t *)e->d_pi, (const int32_t *)s.d_nodes, (const int64_t *)s.d_values, n_pi,
+                               e->d_state, (const int32_t *)s.d_arcs, (const int32_t *)s.d_states, n_st, e->begin, e->count_padded, e->d_rc, e->d_adj_start, e->d_adj);
+        else if (e->d.int_width == 32)
             hipLaunchKernelGGL(update_kernel<int32_t>, dim3(blocks), dim3(kThreads), 0, e->stream, (int32_t *)e->d_pi, (const int32_t *)s.d_nodes,
                                (const int64_t *)s.d_values, n_pi, e->d_state, (const int32_t *)s.d_arcs, (const int32_t *)s.d_states, n_st, e->begin, e->count_padded);
         else
@@ -1090,12 +1225,14 @@ int search_begin(mcf_engine *e)
     }
     e->seq += 1;
     if (e->seq == 0) e->seq = 1;
-    const bool inline_ok = !(e->d.flags & MCF_ENGINE_NO_INLINE_UPDATE) && (int)e->pend_node.size() <= kInlinePi &&
+    // RC layout: a potential change is a shift of the reduced costs of the node's arcs.  A short list with one common shift rides in the
+    // scan's arguments (every workgroup shifts the arcs it scans itself); anything else goes through update_rc_kernel first
+    const bool inline_ok = !(e->d.flags & MCF_ENGINE_NO_INLINE_UPDATE) && (e->rc_mode ? rc_inline_ok(e) : (int)e->pend_node.size() <= kInlinePi) &&
                            (int)e->pend_arc.size() <= kInlineState;
     if (!inline_ok) { int rc = flush_pending(e); if (rc) return rc; }
     const bool timed = (e->d.flags & MCF_ENGINE_TIME_EVERY_KERNEL) ||
                        ((e->d.flags & MCF_ENGINE_SAMPLE_KERNEL_TIME) && (e->st.scan_launches & 15) == 0);
-    int rc = e->d.int_width == 32 ? launch_scan<int32_t>(e, inline_ok, timed) : launch_scan<int64_t>(e, inline_ok, timed);
+    int rc = e->rc_mode ? launch_scan_rc(e, inline_ok, timed) : (e->d.int_width == 32 ? launch_scan<int32_t>(e, inline_ok, timed) : launch_scan<int64_t>(e, inline_ok, timed));
     if (rc) return rc;
     if (inline_ok) {
         if (had) e->st.inline_updates += 1;
@@ -1293,6 +1430,26 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         const int tiles = e->count_padded / (e->unroll * kResidentTile);
         e->grid = std::max(1, std::min(tiles, desc->scan_workgroups > 0 ? desc->scan_workgroups : 256));
     }
+    // RC layout: for arcs that would be streamed from memory for every search anyway (neither register-resident nor beside LDS-resident
+    // potentials) -- what also picks one dispatch per search.  MCF_HIP_RC=1 forces it on any size (tests), MCF_HIP_RC=0 keeps the gathering
+    // scan (and with it the bucketed layout).
+    {
+        bool want = !e->resident_reg && !e->lds_pi;
+        if (const char *u = getenv("MCF_HIP_RC")) want = u[0] == '1' ? true : (u[0] == '0' ? false : want);
+        if (desc->flags & (MCF_ENGINE_NO_INLINE_UPDATE)) want = want && true;
+        e->rc_mode = want;
+        if (e->rc_mode) {
+            // pure streaming: more bytes in flight per thread, the grid sized so that every workgroup gets the same number of trips
+            // measured on config 5's arrays (profiles/r02_rc_layout_scan.txt): 1024 workgroups, one tile per trip -- 14.7 us warm / 16.4 cold
+            // for 81 MB; more workgroups or deeper trips only add launch ramp and tail
+            e->unroll = 1;
+            if (const char *u = getenv("MCF_HIP_UNROLL")) { const int v = atoi(u); if (v == 1 || v == 2 || v == 4) e->unroll = v; }
+            const int groups_rc = std::max(1, e->count_padded / (kTile * e->unroll));
+            const int max_rc = getenv("MCF_HIP_MAXWG") ? max_wg : 1024;
+            e->grid = desc->scan_workgroups > 0 ? std::min(desc->scan_workgroups, kMaxWorkgroups) : std::min(groups_rc, max_rc);
+            e->grid = std::max(1, std::min(e->grid, groups_rc));
+        }
+    }
     e->patch_capacity = 2 * desc->node_count + 256;
     const size_t w = desc->int_width / 8;
     hipError_t err = hipSuccess;
@@ -1303,6 +1460,11 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
     chk(hipMalloc(&e->d_cost, w * e->count_padded));
     chk(hipMalloc((void **)&e->d_state, e->count_padded));
     chk(hipMalloc(&e->d_pi, w * (size_t)desc->node_count));
+    if (e->rc_mode) {
+        chk(hipMalloc((void **)&e->d_rc, sizeof(int64_t) * e->count_padded));
+        chk(hipMalloc((void **)&e->d_adj_start, sizeof(int32_t) * ((size_t)desc->node_count + 1)));
+        chk(hipMalloc((void **)&e->d_adj, sizeof(uint32_t) * (size_t)std::max(1, 2 * count)));
+    }
     chk(hipHostMalloc((void **)&e->h_slots, sizeof(Slot) * kMaxWorkgroups * kSlotStride, hipHostMallocMapped | hipHostMallocCoherent));
     if (err == hipSuccess) {
         memset(e->h_slots, 0, sizeof(Slot) * kMaxWorkgroups * kSlotStride);
@@ -1336,7 +1498,8 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         // arcs that fit neither registers nor (with their potentials) LDS are streamed from memory for every search anyway: one dispatch
         // per search with 2048 workgroups is then faster than 256 resident ones (config 5: 71 vs 85 us per pivot)
         if (!e->resident_reg && !e->lds_pi) want = false;
-        if (env && env[0] == '1') want = true;
+        if (e->rc_mode) want = false;                              // the resident grid scans the gathering layout
+        if (env && env[0] == '1' && !e->rc_mode) want = true;
         if (env && env[0] == '0') want = false;
         // an arc shard is served by a resident grid like a whole instance (every workgroup applies every potential patch, state patches
         // outside the shard are ignored); only the RCCL exchange needs the stream, and mcf_engine_comm_init switches to dispatch mode
@@ -1365,7 +1528,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         // bucketed layout: automatic for large sparse Best-Eligible instances; MCF_HIP_BUCKET_NODES=N forces N nodes per range (0 = off)
         int want = (count >= kBucketMinArcs && desc->node_count > 2 * kBucketNodes) ? kBucketNodes : 0;
         if (const char *u = getenv("MCF_HIP_BUCKET_NODES")) want = std::max(0, atoi(u));
-        const bool tile_loop = !e->lds_pi && !(e->resident_ok && e->resident_reg);
+        const bool tile_loop = !e->lds_pi && !(e->resident_ok && e->resident_reg) && !e->rc_mode;
         if (want > 0 && desc->rule == MCF_RULE_BEST_ELIGIBLE && tile_loop && !e->cand_on) {
             if (hipMalloc((void **)&e->d_orig, sizeof(int32_t) * e->count_padded) == hipSuccess) e->bucket_nodes = want;
         }
@@ -1374,6 +1537,8 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
     e->st.resident = e->resident_ok ? 1 : 0;
     e->st.candidates = e->cand_on ? 1 : 0;
     e->st.bytes_per_scan = (int64_t)(desc->int_width == 64 ? 17 : 13) * count + (int64_t)w * desc->node_count;
+    e->st.scan_bytes_read = e->rc_mode ? (int64_t)9 * count : e->st.bytes_per_scan;
+    e->st.rc_layout = e->rc_mode ? 1 : 0;
     e->st.initial_block_size = e->st.current_block_size = e->block_size;
     *out = e;
     return MCF_OK;
@@ -1399,6 +1564,7 @@ void mcf_engine_destroy(mcf_engine *e)
     if (e->res_stop) (void)hipEventDestroy(e->res_stop);
     if (e->comm && rccl() && rccl()->comm_destroy) rccl()->comm_destroy(e->comm);
     if (e->d_orig) (void)hipFree(e->d_orig);
+    (void)hipFree(e->d_rc); (void)hipFree(e->d_adj_start); (void)hipFree(e->d_adj);
     (void)hipFree(e->d_src); (void)hipFree(e->d_tgt); (void)hipFree(e->d_cost); (void)hipFree(e->d_state); (void)hipFree(e->d_pi);
     (void)hipFree(e->d_cand_local); (void)hipFree(e->d_cand_all); (void)hipFree(e->d_flush);
     if (e->h_cand_all) (void)hipHostFree(e->h_cand_all);
@@ -1473,6 +1639,12 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
         for (int i = 0; i < count; ++i) c[at(i)] = cost[e->begin + i];
         HIP_TRY(hipMemcpy(e->d_cost, c.data(), sizeof(int64_t) * cp, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(e->d_pi, pi, sizeof(int64_t) * n, hipMemcpyHostToDevice));
+    }
+    if (e->rc_mode) {
+        int rcr = rc_build_adjacency(e, source + e->begin, target + e->begin);      // arcs keep their own order in this layout: position = arc - begin
+        if (!rcr) rcr = rc_recompute(e);
+        if (rcr) return rcr;
+        HIP_TRY(hipStreamSynchronize(e->stream));
     }
     e->pi.assign(pi, pi + n);
     e->mirror_valid = true;
@@ -1576,6 +1748,8 @@ int mcf_engine_update_potential(mcf_engine *e, int32_t count, const int32_t *nod
         e->pend_val[i] = v;
     }
     for (int i = 0; i < count; ++i) e->pi[nodes[i]] = e->pend_val[i];
+    e->pend_shift = true;
+    e->pend_sigma = sigma;
     e->st.potential_nodes += count;
     return MCF_OK;
 }
@@ -1601,6 +1775,7 @@ int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes,
     if (!e->pend_node.empty()) { int rc = resident_stop(e); if (!rc) rc = flush_pending(e); if (rc) return rc; }
     e->pend_node.assign(nodes, nodes + count);
     e->pend_val.assign(values, values + count);
+    e->pend_shift = false;
     e->mirror_valid = false;
     e->st.potential_nodes += count;
     resident_stream(e);       // a long list starts travelling now; the search only has to finish it
@@ -1627,9 +1802,21 @@ int mcf_engine_append_potential(mcf_engine *e, int32_t count, const int32_t *nod
     }
     e->pend_node.insert(e->pend_node.end(), nodes, nodes + count);
     e->pend_val.insert(e->pend_val.end(), values, values + count);
+    e->pend_shift = false;
     e->mirror_valid = false;
     e->st.potential_nodes += count;
     resident_stream(e);
+    return MCF_OK;
+}
+
+int mcf_engine_shift_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values, int64_t sigma)
+{
+    if (!e) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_shift_potential: bad arguments");
+    const bool first = e->pend_node.empty();
+    const bool same = first || (e->pend_shift && e->pend_sigma == sigma);
+    const int rc = mcf_engine_append_potential(e, count, nodes, values);
+    if (rc) return rc;
+    if (count > 0 && !e->cand_on) { e->pend_shift = same; e->pend_sigma = sigma; }
     return MCF_OK;
 }
 
@@ -1658,6 +1845,16 @@ int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, con
         } else {
             HIP_TRY(hipMemcpy((int64_t *)e->d_cost + l, &cost[i], 8, hipMemcpyHostToDevice));
         }
+    }
+    if (e->rc_mode) {        // end points and costs changed: the arcs' reduced costs and the nodes' arc lists are rebuilt from the device arrays
+        const int cnt = e->end - e->begin;
+        std::vector<int32_t> s2((size_t)std::max(1, cnt)), t2((size_t)std::max(1, cnt));
+        HIP_TRY(hipMemcpy(s2.data(), e->d_src, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(t2.data(), e->d_tgt, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost));
+        int rcr = rc_build_adjacency(e, s2.data(), t2.data());
+        if (!rcr) rcr = rc_recompute(e);
+        if (rcr) return rcr;
+        HIP_TRY(hipStreamSynchronize(e->stream));
     }
     return MCF_OK;
 }
@@ -1845,6 +2042,8 @@ int mcf_engine_reset_stats(mcf_engine *e)
     e->st.initial_block_size = keep.initial_block_size;
     e->st.current_block_size = e->block_size;
     e->st.comm_ranks = keep.comm_ranks;
+    e->st.scan_bytes_read = keep.scan_bytes_read;
+    e->st.rc_layout = keep.rc_layout;
     return MCF_OK;
 }
 
@@ -1875,7 +2074,8 @@ int mcf_engine_bench_scan(mcf_engine *e, int32_t reps, int32_t cold, int64_t flu
         e->seq += 1;
         if (e->seq == 0) e->seq = 1;
         // same dispatch as a search, timed on the engine's stream; the records are simply not merged
-        if (e->d.int_width == 32) { ScanParams<int32_t> p; fill_params(e, p, false); dispatch_scan<int32_t>(e, p, a, b); }
+        if (e->rc_mode) { RcParams p; fill_rc_params(e, p, false); dispatch_scan_rc(e, p, a, b); }
+        else if (e->d.int_width == 32) { ScanParams<int32_t> p; fill_params(e, p, false); dispatch_scan<int32_t>(e, p, a, b); }
         else { ScanParams<int64_t> p; fill_params(e, p, false); dispatch_scan<int64_t>(e, p, a, b); }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventSynchronize(b));

@@ -4,6 +4,7 @@
 //   resident_kernel                 one grid per solve: requests arrive through a mailbox in BAR-mapped VRAM; arcs (REG) and the potentials of
 //                                   their end points (PIREG) live in registers, or all potentials in LDS (LPI); CAND adds a candidate list
 //   update_kernel                   long patch lists in dispatch mode
+//   scan_rc_kernel / update_rc_kernel  large sparse instances: reduced costs kept per arc, the scan streams 9 bytes per arc and gathers nothing
 // PERM variants read arcs stored in bucketed order (sorted by target-node range) and break ties through the original arc ids.
 // No MFMA: there is no contraction on this path; it is bound by memory bandwidth, gather throughput and host <-> device latency.
 #pragma once
@@ -323,6 +324,155 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(const ScanParams<T> p)
     }
     if (PERM && best.p != kNone) best.p = (uint32_t)p.orig[(int)best.p - p.base];     // position -> arc id; from here on everything is as without PERM
     publish_best<RULE, false>(best, p.slots + (size_t)blockIdx.x * kSlotStride, p.seq, true);
+}
+
+// ------------------------------------------------------------------------------------------------ reduced costs kept per arc (RC layout)
+// Large sparse instances (arcs in neither registers nor LDS: config 5) spend their scan on the two potential gathers per arc: 16 useful
+// bytes fetched as two whole cache lines from an 8 MB table, L2 -> L1 bandwidth bound (27-33 % of the HBM rate for the 17 streamed bytes).
+// In this layout the engine keeps d[e] = cost[e] + pi[source[e]] - pi[target[e]] per arc and the scan streams state (1 B) + d (8 B): no
+// gather at all.  The gathers move to the potential update, where they are scatters over the MOVED nodes' arcs only: update_rc_kernel
+// adds the node's change to d of its out-arcs and subtracts it from d of its in-arcs (integer atomics: exact in any order; an arc inside
+// the moved subtree gets +delta and -delta).  Same reduced costs, bit for bit, same keys, same tie-breaks (arcs keep their own order).
+template <int RULE, bool OPT>
+__device__ __forceinline__ void fold_rc(uint32_t st4, const int64_t d[4], int e0, int m_s, int next_arc, int block_size, int rstar, Key &best)
+{
+    uint32_t pos0 = 0;
+    if (RULE != MCF_RULE_BEST_ELIGIBLE) {
+        int q = e0 - next_arc;
+        if (q < 0) q += m_s;
+        pos0 = (uint32_t)q;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int st = (int)(int8_t)(st4 >> (8 * j));
+        const int64_t rc = st > 0 ? d[j] : (st < 0 ? -d[j] : 0);
+        if (RULE == MCF_RULE_BEST_ELIGIBLE) {
+            if (rc < best.c) { best.c = rc; best.p = (uint32_t)(e0 + j); }   // strict <: lowest arc wins ties
+        } else {
+            uint32_t pos = pos0 + j;
+            if (pos >= (uint32_t)m_s) pos -= (uint32_t)m_s;
+            if (RULE == MCF_RULE_FIRST_ELIGIBLE) {
+                if (rc < 0) take_if_better<RULE>(best, rc, 0u, pos);
+            } else {
+                uint32_t r = pos / (uint32_t)block_size;
+                r = 2 * r + ((OPT && (int)r == rstar && e0 + j < next_arc) ? 1u : 0u);
+                if (rc < 0) take_if_better<RULE>(best, rc, r, pos);
+            }
+        }
+    }
+}
+
+constexpr int kRcInlineNodes = 64;          // moved nodes whose change rides in the scan's arguments ...
+constexpr int kRcInlineEntries = 4096;      // ... when their arc lists together are no longer than this
+
+struct RcParams {
+    const int8_t *state_ro;
+    int8_t *state;
+    int64_t *rc;
+    Slot *slots;
+    void *pi;                               // device potentials (kept for download / later list updates): workgroup 0 adds the change
+    const uint32_t *adj;
+    int32_t base, count_padded, m_s, next_arc, block_size, rstar;
+    uint32_t seq;
+    int32_t n_st, n_pi, narrow;             // narrow: pi is int32
+    int32_t st_arc[kInlineState];
+    int32_t st_val[kInlineState];
+    int64_t sigma;                          // every moved node's potential changes by this (NS.cs:1185-1209: one sigma per pivot)
+    int32_t pi_node[kRcInlineNodes];
+    int32_t adj_lo[kRcInlineNodes];         // first entry of the node's arc list
+    int32_t prefix[kRcInlineNodes + 1];     // entries before node k's list in the concatenation of the lists
+};
+
+template <int RULE, bool OPT, int UNROLL>
+__global__ __launch_bounds__(kThreads) void scan_rc_kernel(const RcParams p)
+{
+    const int tid = threadIdx.x;
+    if (p.n_st | p.n_pi) {
+        // the State[] writes of the previous pivot: final values, applied by EVERY workgroup before it reads
+        if (tid < p.n_st) {
+            const int a = p.st_arc[tid] - p.base;
+            if ((unsigned)a < (unsigned)p.count_padded) p.state[a] = (int8_t)p.st_val[tid];
+        }
+        // A short potential list: every workgroup walks the moved nodes' arc lists and shifts the reduced costs of the arcs IT scans
+        // (tile t belongs to workgroup t mod grid), so every arc is shifted exactly once, by its only reader, before that reader reads
+        // it -- no ordering between workgroups is needed.  An arc between two moved nodes appears twice (+sigma, -sigma): atomics.
+        const int total = p.n_pi ? p.prefix[p.n_pi] : 0;
+        for (int f = tid; f < total; f += kThreads) {
+            int k = 0;
+            for (int step = kRcInlineNodes / 2; step > 0; step >>= 1)        // largest k with prefix[k] <= f
+                if (k + step < p.n_pi && p.prefix[k + step] <= f) k += step;
+            const uint32_t x = p.adj[p.adj_lo[k] + (f - p.prefix[k])];
+            const uint32_t pos = x & 0x7FFFFFFFu;
+            if ((int)((pos / (uint32_t)(kTile * UNROLL)) % gridDim.x) == (int)blockIdx.x) {
+                const long long add = (x >> 31) ? -p.sigma : p.sigma;
+                atomicAdd(reinterpret_cast<unsigned long long *>(p.rc + pos), (unsigned long long)add);
+            }
+        }
+        if (blockIdx.x == 0 && tid < p.n_pi) {
+            if (p.narrow) reinterpret_cast<int32_t *>(p.pi)[p.pi_node[tid]] += (int32_t)p.sigma;
+            else reinterpret_cast<int64_t *>(p.pi)[p.pi_node[tid]] += p.sigma;
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    }
+    Key best;
+    best.c = 0;
+    best.r = kNone;
+    best.p = kNone;
+    typedef long v2l __attribute__((ext_vector_type(2)));
+    const int step = gridDim.x * kTile * UNROLL;
+    for (int i0 = blockIdx.x * kTile * UNROLL + tid * kArcsPerThread; i0 < p.count_padded; i0 += step) {
+        uint32_t st4[UNROLL];
+        v2l a[UNROLL], b[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {       // streamed once per scan: non-temporal, all loads of the trip in flight together
+            const int i = i0 + u * kTile;
+            st4[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p.state_ro + i));
+            a[u] = __builtin_nontemporal_load(reinterpret_cast<const v2l *>(p.rc + i));
+            b[u] = __builtin_nontemporal_load(reinterpret_cast<const v2l *>(p.rc + i + 2));
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t d[4] = {a[u].x, a[u].y, b[u].x, b[u].y};
+            fold_rc<RULE, OPT>(st4[u], d, p.base + i0 + u * kTile, p.m_s, p.next_arc, p.block_size, p.rstar, best);
+        }
+    }
+    publish_best<RULE, false>(best, p.slots + (size_t)blockIdx.x * kSlotStride, p.seq, true);
+}
+
+// d[e] = cost[e] + pi[source[e]] - pi[target[e]] for every stored arc (upload, mcf_engine_patch_arcs); padding arcs have state 0
+template <typename T>
+__global__ __launch_bounds__(kThreads) void rc_init_kernel(const int32_t *src, const int32_t *tgt, const T *cost, const T *pi, int64_t *rc, int count_padded)
+{
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < count_padded) rc[i] = (int64_t)cost[i] + (int64_t)pi[src[i]] - (int64_t)pi[tgt[i]];
+}
+
+// pi[node[i]] = value[i] and the change carried over to the node's arcs; state[arc[j]] = s[j].  One thread per node: the nodes of a
+// list are distinct (the caller's contract), so every node's change is computed and applied exactly once.
+// adj: the shard's arcs incident to each node as local positions, bit 31 set when the node is the arc's TARGET.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void update_rc_kernel(T *pi, const int32_t *nodes, const int64_t *values, int n_pi, int8_t *state, const int32_t *arcs,
+                                                             const int32_t *states, int n_st, int base, int count_padded, int64_t *rc,
+                                                             const int32_t *adj_start, const uint32_t *adj)
+{
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n_pi) {
+        const int u = nodes[i];
+        const int64_t delta = values[i] - (int64_t)pi[u];
+        pi[u] = (T)values[i];
+        if (delta != 0) {
+            for (int k = adj_start[u], hi = adj_start[u + 1]; k < hi; ++k) {
+                const uint32_t x = adj[k];
+                const long long add = (x >> 31) ? -delta : delta;
+                atomicAdd(reinterpret_cast<unsigned long long *>(rc + (x & 0x7FFFFFFFu)), (unsigned long long)add);
+            }
+        }
+    }
+    if (i < n_st) {
+        const int a = arcs[i] - base;
+        if ((unsigned)a < (unsigned)count_padded) state[a] = (int8_t)states[i];
+    }
 }
 
 // Same scan for graphs whose potential vector fits LDS (node_count <= kLdsPiMax): 1024-thread workgroups copy pi into LDS once

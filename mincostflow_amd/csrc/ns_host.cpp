@@ -95,8 +95,8 @@ int engines_patch_state(mcf_ns *s, int32_t count, const int32_t *arcs, const int
 }
 int engines_append_potential(mcf_ns *s, int32_t count, const int32_t *nodes, const int64_t *values)
 {
-    int rc = mcf_engine_append_potential(s->engine, count, nodes, values); // the potentials are replicated on every shard
-    for (size_t i = 0; i < s->peers.size() && !rc; ++i) rc = mcf_engine_append_potential(s->peers[i], count, nodes, values);
+    int rc = mcf_engine_shift_potential(s->engine, count, nodes, values, s->sigma); // the potentials are replicated on every shard
+    for (size_t i = 0; i < s->peers.size() && !rc; ++i) rc = mcf_engine_shift_potential(s->peers[i], count, nodes, values, s->sigma);
     return rc;
 }
 int engines_search_begin(mcf_ns *s)

@@ -365,6 +365,10 @@ class PivotEngine:
         nodes, values = _i32(nodes), _i64(values)
         L.check(L.lib().mcf_engine_append_potential(self._h, nodes.shape[0], nodes, values))
 
+    def shift_potential(self, nodes, values, sigma: int):
+        nodes, values = _i32(nodes), _i64(values)
+        L.check(L.lib().mcf_engine_shift_potential(self._h, nodes.shape[0], nodes, values, sigma))
+
     def patch_arcs(self, arcs, source, target, cost):
         arcs = _i32(arcs)
         L.check(L.lib().mcf_engine_patch_arcs(self._h, len(arcs), arcs, _i32(source), _i32(target), _i64(cost)))

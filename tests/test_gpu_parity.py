@@ -35,16 +35,27 @@ def _oracle_scan(rule, optimized, a, m_s, block, next_arc):
 # default = resident grid, with the candidate cache where it applies (Best Eligible, register-resident arcs, sparse graph)
 MODES = [pytest.param(M.ENGINE_NO_CANDIDATES, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"), pytest.param(0, id="candidates"),
          pytest.param(M.ENGINE_SHARE_DEVICE | M.ENGINE_NO_CANDIDATES, id="resident-shared"),      # resident grid without register-resident potentials
-         pytest.param(M.ENGINE_SHARE_DEVICE, id="candidates-shared")]
+         pytest.param(M.ENGINE_SHARE_DEVICE, id="candidates-shared"),
+         pytest.param("rc", id="rc-layout")]      # reduced costs kept per arc (what large sparse instances use), forced onto these sizes
 CAND_MODES = (0, M.ENGINE_SHARE_DEVICE)
+
+
+def _mode_flags(mode, monkeypatch):
+    """Engine flags of a MODES entry; "rc" = one dispatch per search over the RC layout (MCF_HIP_RC=1 forces it on any size)."""
+    if mode == "rc":
+        monkeypatch.setenv("MCF_HIP_RC", "1")
+        return M.ENGINE_DISPATCH
+    return mode
 
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("width", [64, 32])
 @pytest.mark.parametrize("rule,optimized", [(O.RULE_BEST, True), (O.RULE_BLOCK, True), (O.RULE_BLOCK, False), (O.RULE_FIRST, True)])
-def test_scan_matches_oracle_on_random_arrays(width, rule, optimized, mode):
+def test_scan_matches_oracle_on_random_arrays(width, rule, optimized, mode, monkeypatch):
     """Ragged sizes, heavy ties (tiny cost range), random patches between searches (short lists, long lists), in both
     engine modes: the resident grid fed through the mailbox and one dispatch per search."""
+    rc_layout = mode == "rc"
+    mode = _mode_flags(mode, monkeypatch)
     rng = np.random.default_rng(1234 + width + 10 * rule + optimized)
     for m_s, n, span in [(1, 2, 3), (3, 2, 2), (4, 5, 2), (5, 3, 50), (1023, 40, 3), (1024, 300, 2), (1025, 7, 10 ** 6),
                          (4097, 5000, 4), (100003, 20000, 10 ** 4), (2 ** 20 + 5, 3000, 10 ** 5),
@@ -87,7 +98,9 @@ def test_scan_matches_oracle_on_random_arrays(width, rule, optimized, mode):
         assert st["searches"] == 12 and st["resident"] == (0 if mode == M.ENGINE_DISPATCH else 1)
         if mode not in CAND_MODES:
             assert st["candidates"] == 0
-        if mode == M.ENGINE_DISPATCH:
+        if rc_layout:
+            assert st["rc_layout"] == 1 and (st["update_launches"] > 0 or n < 100) and st["inline_updates"] > 0 and st["scan_bytes_read"] == 9 * m_s
+        elif mode == M.ENGINE_DISPATCH:
             assert (st["inline_updates"] > 0 and st["update_launches"] > 0) or n < 97
         elif mode in CAND_MODES and rule == O.RULE_BEST and m_s <= 1 << 20 and 2 * m_s <= 24 * n:
             assert st["candidates"] == 1 and st["resident_requests"] + st["host_decided"] >= 12
@@ -149,8 +162,10 @@ def _solve_both(p, sem, rule, int_width=0, flags=0, supply_type=O.GEQ, block_siz
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", ["netgen_8_08a", "netgen_8_10a", "transport_40x30", "circulation_100_0_10", "assignment_50x50",
                                   "SimpleProblemIllustration2NonSparse", "AURV19V6", "grid_5x5", "star_graph"])
-def test_solve_is_pivot_for_pivot_identical(name, mode):
+def test_solve_is_pivot_for_pivot_identical(name, mode, monkeypatch):
     """Same entering arc at every pivot, hence same flows and potentials, for both C# flavours of every rule."""
+    rc_layout = mode == "rc"
+    mode = _mode_flags(mode, monkeypatch)
     p = load(name)
     for sem, rule in [(O.SEM_CSHARP_OPT, O.RULE_BLOCK), (O.SEM_CSHARP, O.RULE_BLOCK), (O.SEM_CSHARP_OPT, O.RULE_BEST),
                       (O.SEM_CSHARP, O.RULE_BEST), (O.SEM_CSHARP_OPT, O.RULE_FIRST), (O.SEM_CSHARP, O.RULE_FIRST)]:
@@ -561,9 +576,11 @@ def test_register_resident_potentials_pivot_for_pivot():
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("m_s,n", [(400003, 100001), (60001, 16000), (1_300_000, 40000)])
-def test_potential_lists_that_arrive_in_pieces(mode, m_s, n):
+def test_potential_lists_that_arrive_in_pieces(mode, m_s, n, monkeypatch):
     """mcf_engine_append_potential: the list of one pivot handed over in several calls (disjoint nodes); in resident mode the complete lines
     travel at once (apply posts) and the search finishes the list.  Every engine mode, potentials in registers / LDS / memory."""
+    rc_layout = mode == "rc"
+    mode = _mode_flags(mode, monkeypatch)
     rng = np.random.default_rng(31 + m_s)
     a = _random_soa(rng, m_s, n, 3, 9)
     eng = M.PivotEngine(n, len(a["src"]), m_s, rule=M.PivotRule.BestEligible, optimized=True, flags=mode)
@@ -587,9 +604,11 @@ def test_potential_lists_that_arrive_in_pieces(mode, m_s, n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", MODES)
-def test_search_in_two_halves(mode):
+def test_search_in_two_halves(mode, monkeypatch):
     """mcf_engine_search_begin / _end: the answer is the blocking call's; patches queued while a search is in flight belong to the next one;
     parking the engine (or reading its statistics) in between keeps the answer."""
+    rc_layout = mode == "rc"
+    mode = _mode_flags(mode, monkeypatch)
     rng = np.random.default_rng(606)
     m_s, n = 120007, 30000
     a = _random_soa(rng, m_s, n, 4, 12)
@@ -621,12 +640,14 @@ def test_search_in_two_halves(mode):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [pytest.param(M.ENGINE_NO_CANDIDATES, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"),
-                                  pytest.param(M.ENGINE_SHARE_DEVICE | M.ENGINE_NO_CANDIDATES, id="resident-shared"), pytest.param(0, id="candidates")])
+                                  pytest.param(M.ENGINE_SHARE_DEVICE | M.ENGINE_NO_CANDIDATES, id="resident-shared"), pytest.param(0, id="candidates"),
+                                  pytest.param("rc", id="rc-layout")])
 @pytest.mark.parametrize("m_s,n", [(400003, 100001), (60001, 16000)])
-def test_state_patch_lists_of_any_length(mode, m_s, n):
+def test_state_patch_lists_of_any_length(mode, m_s, n, monkeypatch):
     """mcf_engine_patch_state with 65, 200 and 5000 distinct arcs between two searches, each time with a potential list pending
     ('Queued; ordered before the next search', include/mcf_hip.h): the resident grid receives them through the mailbox (up to 4096)
     or, beyond that, is stopped first; dispatch mode ships them with update_kernel."""
+    mode = _mode_flags(mode, monkeypatch)
     rng = np.random.default_rng(2024 + m_s)
     a = _random_soa(rng, m_s, n, 3, 9)
     eng = M.PivotEngine(n, len(a["src"]), m_s, rule=M.PivotRule.BestEligible, optimized=True, flags=mode)
@@ -784,7 +805,7 @@ CONFIG5 = (13502460, 1_000_000, 8_000_000, 1000, 1000)
 @pytest.mark.gpu
 def test_config5_solves_end_to_end_and_shards_follow_the_same_pivots():
     """BASELINE.json configs[4] on ONE GPU, end to end: NETGEN-like 1M nodes / 8M arcs, Best Eligible, int64, through mcf_ns_solve with
-    the layout the engine picks by itself at this size (bucketed, one dispatch per search, 2048 records per search).  Checked by
+    the layout the engine picks by itself at this size (reduced costs kept per arc, one dispatch per search, 1024 records per search).  Checked by
       * the device validator's optimality certificate (mcf_ns_validate: conservation, bounds, complementary slackness, primal = dual),
       * the optimal cost of the CPU oracle's Block-Search solve of the same instance (tests/golden/config5_cost.json; 15-20 CPU minutes,
         hence golden -- generated by tests/golden/make_config5_cost.py),
@@ -801,7 +822,7 @@ def test_config5_solves_end_to_end_and_shards_follow_the_same_pivots():
     assert ns.solve() == M.SolverStatus.Optimal
     m = ns.get_metrics()
     assert m["search_arc_num"] == gold["search_arc_num"] == 9_000_000 and m["iterations"] > 1_000_000
-    assert m["engine"]["resident"] == 0 and m["engine"]["scan_workgroups"] == 2048          # what the engine chooses at this size
+    assert m["engine"]["resident"] == 0 and m["engine"]["rc_layout"] == 1 and m["engine"]["scan_workgroups"] == 1024    # what the engine chooses at this size
     cost = ns.get_total_cost()
     assert cost == gold["total_cost"], (cost, gold["total_cost"])
     v = ns.validate()
@@ -824,3 +845,70 @@ def test_config5_solves_end_to_end_and_shards_follow_the_same_pivots():
         assert nsg.solve() == M.SolverStatus.NotSolved
         assert np.array_equal(nsg.trace(), trace), (shards, int(np.argmax(nsg.trace() != trace)))
         del nsg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [pytest.param(M.ENGINE_NO_CANDIDATES, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"), pytest.param(0, id="candidates-or-default"),
+                                  pytest.param("rc", id="rc-layout")])
+def test_patch_arcs_rewrites_end_points_and_costs(mode, monkeypatch):
+    """mcf_engine_patch_arcs (artificial arcs re-pointed by a warm start): source / target / cost of some arcs change between two searches;
+    in the RC layout the per-arc reduced costs and the nodes' arc lists are rebuilt.  The candidate cache refuses (its mirrors are fixed)."""
+    flags = _mode_flags(mode, monkeypatch)
+    rng = np.random.default_rng(808)
+    m_s, n = 70_001, 18_000
+    a = _random_soa(rng, m_s, n, 30, 300)
+    for rule in (O.RULE_BEST, O.RULE_BLOCK):
+        eng = M.PivotEngine(n, len(a["src"]), m_s, rule=RULES[rule], optimized=True, block_size=211, flags=flags)
+        eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+        next_arc = 0
+        for it in range(6):
+            f, e, c, na = _oracle_scan(rule, True, a, m_s, 211, next_arc)
+            assert eng.find_entering() == (f, e, c), it
+            next_arc = na
+            arcs = rng.choice(len(a["src"]), size=int(rng.choice([1, 5, 40])), replace=False).astype(np.int32)
+            src = rng.integers(0, n, len(arcs)).astype(np.int32); tgt = rng.integers(0, n, len(arcs)).astype(np.int32)
+            cost = rng.integers(-30, 31, len(arcs)).astype(np.int64)
+            if eng.stats()["candidates"]:
+                with pytest.raises(M.McfError):
+                    eng.patch_arcs(arcs, src, tgt, cost)
+                break
+            a["src"][arcs] = src; a["tgt"][arcs] = tgt; a["cost"][arcs] = cost
+            eng.patch_arcs(arcs, src, tgt, cost)
+            nodes = rng.choice(n, size=int(rng.choice([1, 200])), replace=False).astype(np.int32)
+            a["pi"][nodes] += 2
+            eng.update_potential(nodes, 2)
+        assert np.array_equal(eng.download_pi(), a["pi"])
+
+
+@pytest.mark.gpu
+def test_rc_layout_shards_and_shard_group(monkeypatch):
+    """Arc shards in the RC layout: every shard keeps the reduced costs of ITS arcs and the arc lists of all nodes restricted to them."""
+    monkeypatch.setenv("MCF_HIP_RC", "1")
+    rng = np.random.default_rng(5150)
+    m_s, n, world = 120_003, 25_000, 3
+    a = _random_soa(rng, m_s, n, 4, 12, extra=0)
+    shards = []
+    for r in range(world):
+        e = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible, optimized=True, shard=M.shard_range(m_s, r, world), flags=M.ENGINE_DISPATCH)
+        e.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+        assert e.stats()["rc_layout"] == 1
+        shards.append(e)
+    for it in range(10):
+        f, arc, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+        cands = [e.find_entering_local() for e in shards]
+        got = [e.resolve(cands) for e in shards]
+        assert all(g[0] == f and (not f or (g[1], g[2]) == (arc, c)) for g in got), (it, got, arc, c)
+        arcs = rng.choice(m_s, size=3, replace=False).astype(np.int32); vals = rng.integers(-1, 2, 3).astype(np.int8)
+        a["state"][arcs] = vals
+        nodes = rng.choice(n, size=int(rng.choice([1, 40, 5000])), replace=False).astype(np.int32)
+        a["pi"][nodes] -= 2
+        for e in shards:
+            e.patch_state(arcs, vals)
+            e.update_potential(nodes, -2)
+    p = load("netgen_8_14a")
+    o = O.Oracle(p, O.SEM_CSHARP_OPT, O.RULE_BEST)
+    st_o, tr_o = o.solve(trace_cap=1 << 22)
+    ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True)
+    ns.set_shard_group([0, 0]).record_trace(1 << 22)
+    assert ns.solve() == st_o == O.OPTIMAL and np.array_equal(ns.trace(), tr_o)
+    assert ns.get_metrics()["engine"]["rc_layout"] == 1
