@@ -39,7 +39,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
 SEED = 13502460
-TRAFFIC_FILE = "traffic_r01.json"   # PMC FETCH_SIZE of a separate rocprofv3 --pmc pass (gpurun refuses --pmc beside tracing)
+TRAFFIC_FILE = "traffic_r02.json"   # PMC FETCH_SIZE of a separate rocprofv3 --pmc pass (gpurun refuses --pmc beside tracing)
 
 
 def parse():
