@@ -246,6 +246,19 @@ def large_instance_sample(M, local_rank, with_cpu, gpu_pivots=3000, cpu_seconds=
            "search_arcs": m["search_arc_num"], "bytes_read_per_scan": m["engine"]["scan_bytes_read"],
            "scan_GBps_incl_round_trip": m["engine"]["scan_bytes_read"] / (m["pivot_search_us"] / it) / 1e3}
     del ns
+    # the same pivots with the arcs as 8 shards driven by ONE host thread, all eight engines on this one GPU (a rehearsal of mcf_ns_set_shard_group:
+    # eight dispatches share the device, so this is the host-side cost of the sharded path plus 8 x a ninth of the scan, not a scaling figure)
+    try:
+        nsg = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).set_device(local_rank, 64, 0, 0)
+        nsg.set_shard_group([local_rank] * 8).set_pivot_limit(gpu_pivots).prepare()
+        nsg.solve()
+        mg = nsg.get_metrics(); itg = max(mg["iterations"], 1)
+        out["as_8_shards_on_this_one_gpu"] = {"pivots": mg["iterations"], "us_per_pivot": mg["loop_us"] / itg, "pivot_search_us": mg["pivot_search_us"] / itg,
+                                              "what": "mcf_ns_set_shard_group([gpu] * 8): one host thread posts each search to 8 engines (1.125 M arcs each, RC layout, one dispatch "
+                                                      "each) and reduces their 8 answers; on 8 GPUs the 8 dispatches run side by side"}
+        del nsg
+    except M.McfError as err:
+        out["as_8_shards_on_this_one_gpu"] = {"error": str(err)}
     if with_cpu:
         b = cpu_baseline(g5, M.PivotRule.BestEligible, cpu_seconds)
         out["cpu_port_same_rule"] = {"us_per_pivot": b["us_per_pivot"], "sample": b["sample"], "cores": 1}

@@ -190,7 +190,7 @@ struct mcf_engine {
     bool async_posted = false;                    // a refresh is on its way while the host keeps answering from the current list
     uint32_t async_at = 0, posted_at = 0;
     int patch_capacity = 0;                       // potential patches one request / one staged update can carry (2 * node_count + 256)
-    int cand_max_nodes = 48, cand_refresh_low = 12;
+    int cand_max_nodes = 96, cand_refresh_low = 12;
     // where the host's time goes in candidate mode (TSC ticks; printed by mcf_engine_destroy when MCF_HIP_CAND_DEBUG is set)
     double tk_absorb = 0, tk_decide = 0, tk_post = 0, tk_collect = 0, tk_probe = 0;
     int64_t n_sync_posts = 0, n_async_waits = 0, n_gap_pivots = 0, n_heap_push = 0, n_heap_pop = 0, n_list_skip = 0;
@@ -705,7 +705,11 @@ void resident_post(mcf_engine *e, uint32_t seq, uint32_t cmd, bool with_patches)
 // Long potential lists start travelling while the host is still producing them (mcf_engine_append_potential): the complete entry lines
 // gathered so far go into the mailbox and an "apply" post (cmd 2) tells the grid how far the list of the COMING scan request reaches.
 // No answer is expected; the posts are cumulative and the scan request finishes the list (kernels.hip.h, mailbox layout).
-constexpr int kStreamMinLines = 768;           // 3840 entries per post at least: one piece of the host driver's walk (4096 nodes)
+int stream_min_lines()                         // 1920 entries per post at least by default: one piece of the host driver's walk (2048 nodes)
+{
+    static const int v = [] { int x = 384; if (const char *u = getenv("MCF_HIP_STREAM_LINES")) { const int y = atoi(u); if (y >= 16 && y <= 65536) x = y; } return x; }();
+    return v;
+}
 
 void resident_stream(mcf_engine *e)
 {
@@ -715,7 +719,7 @@ void resident_stream(mcf_engine *e)
     if (!e->resident_running || e->in_flight != mcf_engine::kNoSearch) return;
     const int n_pi = (int)e->pend_node.size();
     const int complete = (n_pi > 1 ? n_pi - 1 : 0) / kMailboxPatchesPerLine;
-    if (complete - e->stream_lines < kStreamMinLines) return;
+    if (complete - e->stream_lines < stream_min_lines()) return;
     uint32_t next_seq = e->seq + 1;
     if (next_seq == 0) next_seq = 1;
     alignas(16) uint32_t line[16], line1[16];

@@ -369,7 +369,11 @@ void rehang_subtree(mcf_ns *s)
 //    prefetches the lines it will need kWalkAhead steps from now; a stale hint costs a useless prefetch, nothing else.
 // The order of the resulting list is irrelevant to the engine (final values).
 constexpr int kWalkAhead = 8, kWalkHintMin = 48;
-constexpr int kWalkPiece = 4096;   // a big walk hands its nodes to the engine in pieces of this size (mcf_engine_append_potential);
+int walk_piece()                   // a big walk hands its nodes to the engine in pieces of this size (2048; mcf_engine_append_potential);
+{
+    static const int v = [] { int x = 2048; if (const char *u = getenv("MCF_NS_WALK_PIECE")) { const int y = atoi(u); if (y >= 64 && y <= (1 << 20)) x = y; } return x; }();
+    return v;
+}
                                    // 1024 .. 8192 measure alike on config 3, no hand-over at all costs 0.9 us per pivot
 
 void shift_potentials(mcf_ns *s)
@@ -396,6 +400,7 @@ void shift_potentials(mcf_ns *s)
     }
     int32_t *const follow = s->follow.data();
     int a = s->u_out;
+    const int piece = walk_piece();
     for (int i = 0; i < count; ++i) {
         const int h = follow[a];
         __builtin_prefetch(&nxt[h]);
@@ -405,7 +410,7 @@ void shift_potentials(mcf_ns *s)
         vals[i] = (pi[a] += sigma);
         if (i >= kWalkAhead) follow[nodes[i - kWalkAhead]] = a;
         a = nxt[a];
-        if (s->hand_over && i + 1 - s->moved_sent >= kWalkPiece && count - (i + 1) >= kWalkPiece / 2) {
+        if (s->hand_over && i + 1 - s->moved_sent >= piece && count - (i + 1) >= piece / 2) {
             // the grid applies this piece while the walk goes on (resident mode); the search after the pivot finishes the list
             if (!s->engine_rc) s->engine_rc = engines_append_potential(s, i + 1 - s->moved_sent, nodes + s->moved_sent, vals + s->moved_sent);
             s->moved_sent = i + 1;
