@@ -367,6 +367,11 @@ MCF_API int mcf_ns_finish(mcf_ns *s, int32_t *status);           /* CheckFeasibi
 /* views of the internal SoA after mcf_ns_begin (valid until destroy); sizes: arc_capacity / node_count + 1 */
 MCF_API int mcf_ns_internal(mcf_ns *s, int32_t *search_arc_num, int32_t *arc_capacity, const int32_t **source,
                             const int32_t **target, const int64_t **cost, const int8_t **state, const int64_t **pi);
+/* views of the spanning tree after mcf_ns_begin / mcf_ns_apply_pivot (valid until the next pivot; node arrays: node_count + 1 entries, the last
+ * one is the artificial root; arc arrays: arc_capacity entries): Parent, Pred, SuccNum, PredDir of SpanningTree.cs:10-35 and _flow / _upper.
+ * For tools that study the cycle search (NS.cs:925-1010) on real trees; any pointer may be NULL. */
+MCF_API int mcf_ns_tree(mcf_ns *s, const int32_t **parent, const int32_t **pred_arc, const int32_t **succ_num, const int8_t **pred_dir,
+                        const int64_t **flow, const int64_t **upper);
 /* what the last mcf_ns_apply_pivot changed: the engine calls a host would make */
 MCF_API int mcf_ns_last_pivot(mcf_ns *s, int32_t *n_state, int32_t arcs[2], int8_t states[2], int32_t *n_nodes,
                               const int32_t **nodes, int64_t *sigma);

@@ -187,6 +187,7 @@ SIGNATURES = {
     "mcf_ns_finish": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "mcf_ns_internal": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(_P(C.c_int32)), _P(_P(C.c_int32)),
                                   _P(_P(C.c_int64)), _P(_P(C.c_int8)), _P(_P(C.c_int64))]),
+    "mcf_ns_tree": (C.c_int, [C.c_void_p, _P(_P(C.c_int32)), _P(_P(C.c_int32)), _P(_P(C.c_int32)), _P(_P(C.c_int8)), _P(_P(C.c_int64)), _P(_P(C.c_int64))]),
     "mcf_ns_last_pivot": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int8), _P(C.c_int32),
                                     _P(_P(C.c_int32)), _P(C.c_int64)]),
     "mcf_validator_create": (C.c_int, [_P(C.c_void_p), C.c_int32, C.c_int32, C.c_int32]),

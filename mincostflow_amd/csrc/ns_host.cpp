@@ -688,6 +688,20 @@ int mcf_ns_internal(mcf_ns *s, int32_t *search_arc_num, int32_t *arc_capacity, c
     return MCF_OK;
 }
 
+int mcf_ns_tree(mcf_ns *s, const int32_t **parent, const int32_t **pred_arc, const int32_t **succ_num, const int8_t **pred_dir,
+                const int64_t **flow, const int64_t **upper)
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    if (!s->transformed) return mcf::fail(MCF_ERR_STATE, "mcf_ns_begin has not been called");
+    if (parent) *parent = s->par.data();
+    if (pred_arc) *pred_arc = s->par_arc.data();
+    if (succ_num) *succ_num = s->sub.data();
+    if (pred_dir) *pred_dir = s->par_dir.data();
+    if (flow) *flow = s->flow.data();
+    if (upper) *upper = s->upper.data();
+    return MCF_OK;
+}
+
 int mcf_ns_last_pivot(mcf_ns *s, int32_t *n_state, int32_t arcs[2], int8_t states[2], int32_t *n_nodes, const int32_t **nodes, int64_t *sigma)
 {
     if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");

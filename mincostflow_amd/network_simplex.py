@@ -258,6 +258,15 @@ class NetworkSimplex:
         return dict(search_arc_num=ms.value, arc_capacity=a, source=cp(ps, a), target=cp(pt, a), cost=cp(pc, a),
                     state=cp(pst, a), pi=cp(ppi, n1))
 
+    def tree(self) -> dict:
+        """Copies of Parent, Pred, SuccNum, PredDir (node_count + 1 entries) and the internal flow / upper arrays (arc_capacity entries)."""
+        par, pred, succ = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        pdir, flow, upper = C.POINTER(C.c_int8)(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)()
+        L.check(L.lib().mcf_ns_tree(self._h, C.byref(par), C.byref(pred), C.byref(succ), C.byref(pdir), C.byref(flow), C.byref(upper)))
+        n1, a = self.node_count + 1, self.arc_count + 2 * self.node_count
+        cp = lambda p, k: np.ctypeslib.as_array(p, shape=(k,)).copy()
+        return dict(parent=cp(par, n1), pred_arc=cp(pred, n1), succ_num=cp(succ, n1), pred_dir=cp(pdir, n1), flow=cp(flow, a), upper=cp(upper, a))
+
     def last_pivot(self) -> dict:
         ns, nn, sigma = C.c_int32(), C.c_int32(), C.c_int64()
         arcs, states = (C.c_int32 * 2)(), (C.c_int8 * 2)()
