@@ -133,8 +133,11 @@ def sharded_leg(M, torch, dist, args, rank, world, dev, barrier, red_dev):
     P = args.sharded_pivots
     g5 = M.netgen_like(SEED, 1_000_000, 8_000_000, 1000, 1000)
 
+    # ranks that share a GPU (gloo rehearsal) cannot all keep a full resident grid on it: one dispatch per search there
+    shard_flags = M.ENGINE_DISPATCH if world > M.device_count() else 0
+
     def run(configure):
-        ns5 = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).set_device(dev, 64, 0, 0)
+        ns5 = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).set_device(dev, 64, 0, shard_flags)
         configure(ns5)
         ns5.set_pivot_limit(P).record_trace(P).prepare()
         barrier()                                  # also: every rank has opened the exchange before the first pivot

@@ -96,7 +96,8 @@ typedef struct mcf_engine_desc {
     int32_t scan_workgroups;  /* 0 = auto; otherwise the grid of the scan kernel */
     int32_t flags;            /* MCF_ENGINE_* */
     int32_t resident_workgroups;  /* 0 = auto (one workgroup per CU, at most 256); otherwise a cap on the resident grid: engines that share
-                                     a device (arc shards rehearsed on one GPU) must all be co-resident to answer */
+                                     a device (arc shards rehearsed on one GPU) must all be co-resident to answer.  Workgroups are dealt
+                                     to the 8 XCDs round-robin, so give k engines 8 * (32 / k) each, not 256 / k */
 } mcf_engine_desc;
 
 #define MCF_ENGINE_SAMPLE_KERNEL_TIME 1   /* time every 16th scan dispatch with HIP events */

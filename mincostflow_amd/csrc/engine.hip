@@ -106,6 +106,8 @@ struct mcf_engine {
     int32_t *d_orig = nullptr;     // local position -> global arc id
     // RC layout (kernels.hip.h): reduced costs kept per arc, maintained by scatter from the moved nodes; the scan gathers nothing
     bool rc_mode = false;
+    bool rc_lds = false;           // resident RC grid: every workgroup's window of arcs fits LDS
+    int rc_window = 0;             // arcs per workgroup in that case
     int64_t *d_rc = nullptr;
     int32_t *d_adj_start = nullptr;
     uint32_t *d_adj = nullptr;     // the shard's arcs at each node: local position, bit 31 = the node is the arc's target
@@ -565,6 +567,33 @@ void launch_resident_r(mcf_engine *e, const ResidentParams<T> &p)
     }
 }
 
+template <int RULE, bool OPT>
+void launch_resident_rc_r(mcf_engine *e, const ResidentRcParams &p)
+{
+    const dim3 grid(e->res_grid), block(e->res_threads);
+    if (e->rc_lds) hipExtLaunchKernelGGL((resident_rc_kernel<RULE, OPT, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    else hipExtLaunchKernelGGL((resident_rc_kernel<RULE, OPT, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+}
+
+int launch_resident_rc(mcf_engine *e, uint32_t start_seq)
+{
+    ResidentRcParams p;
+    p.state = e->d_state; p.rc = e->d_rc; p.pi = e->d_pi; p.adj_start = e->d_adj_start; p.adj = e->d_adj; p.slots = e->d_slots;
+    p.mailbox = e->mailbox; p.exit_word = e->d_exit;
+    p.base = e->begin; p.count_padded = e->count_padded; p.m_s = e->d.search_arc_num; p.window = e->rc_window;
+    p.start_seq = start_seq; p.idle_ticks = kResidentIdleTicks; p.narrow = e->d.int_width == 32 ? 1 : 0;
+    p.max_pi = kRcResidentNodes; p.max_st = e->mailbox_max_st; p.poll_replicas = e->poll_replicas; p.poll_sleep = e->poll_sleep;
+    switch (e->d.rule) {
+    case MCF_RULE_BEST_ELIGIBLE: launch_resident_rc_r<MCF_RULE_BEST_ELIGIBLE, false>(e, p); break;
+    case MCF_RULE_FIRST_ELIGIBLE: launch_resident_rc_r<MCF_RULE_FIRST_ELIGIBLE, false>(e, p); break;
+    default:
+        if (e->d.semantics == MCF_SEM_OPTIMIZED) launch_resident_rc_r<MCF_RULE_BLOCK_SEARCH, true>(e, p);
+        else launch_resident_rc_r<MCF_RULE_BLOCK_SEARCH, false>(e, p);
+    }
+    HIP_TRY(hipGetLastError());
+    return MCF_OK;
+}
+
 template <typename T>
 int launch_resident(mcf_engine *e, uint32_t start_seq)
 {
@@ -625,7 +654,7 @@ int resident_start(mcf_engine *e, uint32_t start_seq)
         }
     }
     for (int i = 0; i < 4; ++i) ((volatile uint32_t *)e->h_exit)[i] = 0;
-    int rc = e->d.int_width == 32 ? launch_resident<int32_t>(e, start_seq) : launch_resident<int64_t>(e, start_seq);
+    int rc = e->rc_mode ? launch_resident_rc(e, start_seq) : (e->d.int_width == 32 ? launch_resident<int32_t>(e, start_seq) : launch_resident<int64_t>(e, start_seq));
     if (rc) return rc;
     e->resident_running = true;
     e->st.resident_launches += 1;
@@ -716,7 +745,7 @@ void resident_stream(mcf_engine *e)
     // candidate mode: only one pivot's own big list travels ahead (its entries are final and repeat no node), and never beside a list refresh
     // that is still on its way (the mailbox holds one request)
     if (e->cand_on ? (e->async_posted || e->blind_epoch != e->cand_now || e->blind_sets > 1) : e->pend_arc.size() > 2) return;
-    if (!e->resident_running || e->in_flight != mcf_engine::kNoSearch) return;
+    if (!e->resident_running || e->rc_mode || e->in_flight != mcf_engine::kNoSearch) return;
     const int n_pi = (int)e->pend_node.size();
     const int complete = (n_pi > 1 ? n_pi - 1 : 0) / kMailboxPatchesPerLine;
     if (complete - e->stream_lines < stream_min_lines()) return;
@@ -1204,7 +1233,14 @@ int search_begin(mcf_engine *e)
     }
     if (resident_now) {
         // ---- resident mode: post the request into the mailbox, the grid is already running
-        const bool fits = (int)e->pend_arc.size() <= e->mailbox_max_st;     // any number of potentials fits the mailbox
+        bool fits = (int)e->pend_arc.size() <= e->mailbox_max_st;     // any number of potentials fits the mailbox
+        if (e->rc_mode) {
+            // resident RC grid: a request is one staging chunk of {node, shift} entries; anything else goes through update_rc_kernel with the grid stopped
+            const int64_t n_pi = (int64_t)e->pend_node.size(), n_st = (int64_t)e->pend_arc.size();
+            fits = (n_pi == 0 || e->pend_shift) && n_pi <= kRcResidentNodes &&
+                   (n_pi > 1 ? n_pi - 1 : 0) + (n_st > 2 ? n_st - 2 : 0) <= (int64_t)(kMailboxLines - 1) * kMailboxPatchesPerLine;
+            if (fits && n_pi > 0) std::fill(e->pend_val.begin(), e->pend_val.end(), e->pend_sigma);      // the entries carry the shift, not the value
+        }
         if (!fits) {
             // a list that does not fit the mailbox: stop the grid, ship it with update_kernel, start again
             int rc = resident_stop(e);
@@ -1502,8 +1538,11 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         // arcs that fit neither registers nor (with their potentials) LDS are streamed from memory for every search anyway: one dispatch
         // per search with 2048 workgroups is then faster than 256 resident ones (config 5: 71 vs 85 us per pivot)
         if (!e->resident_reg && !e->lds_pi) want = false;
-        if (e->rc_mode) want = false;                              // the resident grid scans the gathering layout
+        // the RC layout has its own resident grid (resident_rc_kernel): windows of arcs in LDS when they fit, streamed otherwise
+        bool rc_resident = e->rc_mode && (desc->flags & MCF_ENGINE_DISPATCH) == 0 && !(getenv("MCF_HIP_RC_RESIDENT") && getenv("MCF_HIP_RC_RESIDENT")[0] == '0');
+        if (e->rc_mode) want = rc_resident;
         if (env && env[0] == '1' && !e->rc_mode) want = true;
+        (void)rc_resident;
         if (env && env[0] == '0') want = false;
         // an arc shard is served by a resident grid like a whole instance (every workgroup applies every potential patch, state patches
         // outside the shard are ignored); only the RCCL exchange needs the stream, and mcf_engine_comm_init switches to dispatch mode
@@ -1521,6 +1560,17 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
                 for (size_t l = 0; l < (size_t)kMailboxTail / 16 + e->mailbox_lines; ++l) mailbox_write_line(e->mailbox + 16 * l, zero);
                 _mm_sfence();
                 e->resident_ok = true;
+                if (e->rc_mode) {
+                    // one 1024-thread workgroup per CU; a window of at most kRcWindow arcs per workgroup stays in LDS
+                    const int max_grid = desc->resident_workgroups > 0 ? std::min(desc->resident_workgroups, kResidentMaxGrid) : kResidentMaxGrid;
+                    e->res_threads = kResidentThreads;
+                    e->res_grid = std::max(1, std::min(max_grid, e->count_padded / kResidentTile));
+                    const int64_t per = ((int64_t)e->count_padded + e->res_grid - 1) / e->res_grid;
+                    e->rc_window = (int)((per + kResidentTile - 1) / kResidentTile * kResidentTile);
+                    e->rc_lds = e->rc_window <= kRcWindow && !(getenv("MCF_HIP_RC_LDS") && getenv("MCF_HIP_RC_LDS")[0] == '0');
+                    if (!e->rc_lds) e->rc_window = 0;
+                    e->resident_reg = false;
+                }
                 e->cand_on = !(desc->flags & MCF_ENGINE_NO_CANDIDATES) && !(getenv("MCF_HIP_CANDIDATES") && getenv("MCF_HIP_CANDIDATES")[0] == '0') &&
                              whole && e->resident_reg && desc->rule == MCF_RULE_BEST_ELIGIBLE &&
                              2 * (int64_t)desc->search_arc_num <= (int64_t)kCandMaxAvgDegree * desc->node_count;

@@ -924,6 +924,223 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
     }
 }
 
+// ------------------------------------------------------------------------------------------------ resident grid over the RC layout
+// The RC layout's scan (scan_rc_kernel) still pays one dispatch per search (about 6.5 us + 3 us of host launch on a 3-15 us scan).  This grid
+// serves the searches through the same mailbox as resident_kernel:
+//   LD = true   the workgroup's window of arcs (up to kRcWindow: state + reduced cost, 9 B per arc) lives in LDS -- an arc shard of a large
+//               instance (config 5 over 8 GPUs: 1.125 M arcs) is scanned without touching memory;
+//   LD = false  the windows are streamed from memory for every request (a whole large instance on one GPU).
+// A request carries the State[] writes and the MOVED NODES WITH THEIR SHIFT ({node, delta} where resident_kernel gets {node, value}); every
+// workgroup walks the moved nodes' arc lists and shifts the arcs of its own window (LDS copy and memory), so every arc is shifted exactly once,
+// by its only reader.  A request fits one staging chunk (kRcResidentNodes nodes); the host sends longer lists through update_rc_kernel with the
+// grid stopped.
+constexpr int kRcWindow = 8192;                    // arcs per workgroup in LDS: 64 KB of reduced costs + 8 KB of states
+constexpr int kRcResidentNodes = 1 + 255 * kMailboxPatchesPerLine - 8;   // one chunk of entry lines, a few entries left for state patches
+
+struct ResidentRcParams {
+    int8_t *state;
+    int64_t *rc;
+    void *pi;
+    const int32_t *adj_start;
+    const uint32_t *adj;
+    Slot *slots;
+    const uint32_t *mailbox;
+    uint32_t *exit_word;
+    int32_t base, count_padded, m_s, window;       // window: arcs per workgroup (LD), multiple of 4 * blockDim
+    uint32_t start_seq, idle_ticks;
+    int32_t narrow, max_pi, max_st, poll_replicas, poll_sleep;
+};
+
+template <int RULE, bool OPT, bool LD>
+__global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const ResidentRcParams p)
+{
+    constexpr int kLines = kMailboxLines;                      // line 0 + one chunk of 255 entry lines
+    constexpr int kNodesMax = 1280;
+    __shared__ __attribute__((aligned(16))) uint32_t lm[kLines * 16];
+    __shared__ __attribute__((aligned(16))) int64_t ld[LD ? kRcWindow : 2];      // reduced costs of my window
+    __shared__ __attribute__((aligned(16))) int8_t ls[LD ? kRcWindow : 4];       // their states
+    __shared__ int32_t s_node[kNodesMax], s_lo[kNodesMax], s_pre[kNodesMax + 1];
+    __shared__ int64_t s_delta[kNodesMax];
+    __shared__ uint32_t s_timeout;
+    const int tid = threadIdx.x, nt = (int)blockDim.x;
+    const int w_lo = LD ? (int)blockIdx.x * p.window : 0;                       // first position of my window
+    if (LD) {
+        for (int i = tid * 4; i < p.window; i += nt * 4) {
+            const int g = w_lo + i;
+            typedef long v2l __attribute__((ext_vector_type(2)));
+            if (g < p.count_padded) {
+                *reinterpret_cast<v2l *>(ld + i) = *reinterpret_cast<const v2l *>(p.rc + g);
+                *reinterpret_cast<v2l *>(ld + i + 2) = *reinterpret_cast<const v2l *>(p.rc + g + 2);
+                *reinterpret_cast<uint32_t *>(ls + i) = *reinterpret_cast<const uint32_t *>(p.state + g);
+            } else {
+                ld[i] = ld[i + 1] = ld[i + 2] = ld[i + 3] = 0;
+                *reinterpret_cast<uint32_t *>(ls + i) = 0u;
+            }
+        }
+        __syncthreads();
+    }
+    uint32_t last = p.start_seq, served = 0;
+    uint64_t scan_ticks = 0;
+    uint64_t idle_since = __builtin_amdgcn_s_memrealtime();
+    const uint32_t *const my_unit = p.mailbox + (size_t)(blockIdx.x % p.poll_replicas) * kReplicaStride;
+    for (;;) {
+        if (tid < 64) {                                        // wave 0 polls lines 0 and 1 (see resident_kernel)
+            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+            v4u x = v4u{0u, 0u, 0u, 0u};
+            uint32_t flag;
+            for (;;) {
+                if (tid < 8) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x) : "v"(my_unit + tid * 4) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)::"memory");
+                const uint32_t seq0 = lane_u32(x[0], 0), tag0 = lane_u32(x[3], 3);
+                if (seq0 != last && tag0 == seq0) { flag = 1u; break; }
+                if (__builtin_amdgcn_s_memrealtime() - idle_since > p.idle_ticks) { flag = 2u; break; }
+                for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+            }
+            if (tid < 8) *reinterpret_cast<v4u *>(lm + tid * 4) = x;
+            if (tid == 0) s_timeout = flag;
+        }
+        __syncthreads();
+        const uint32_t seq = lm[0], cmd = lm[1];
+        int n_pi = (int)lm[4], n_st = (int)lm[5];
+        n_pi = n_pi < 0 ? 0 : (n_pi > p.max_pi ? p.max_pi : n_pi);
+        n_st = n_st < 0 ? 0 : (n_st > p.max_st ? p.max_st : n_st);
+        const int extra_pi = n_pi > 1 ? n_pi - 1 : 0, extra_st = n_st > 2 ? n_st - 2 : 0, entries = extra_pi + extra_st;
+        const int lines = 1 + (entries + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;      // <= kLines by the host's contract
+        const bool timed_out = s_timeout == 2u;
+        const bool line1_staged = lm[31] == seq;
+        const int next_arc = (int)lm[2], rstar = (int)lm[3];
+        const int block_size = (int)lm[13] > 0 ? (int)lm[13] : 1;
+        const int st_arc0 = (int)lm[6], st_arc1 = (int)lm[8];
+        const uint32_t st_val0 = lm[7], st_val1 = lm[9];
+        const uint32_t p0_node = lm[10], p0_lo = lm[11], p0_hi = lm[12];
+        if (lines > 1) __syncthreads();
+        if (timed_out) {
+            if (tid == 0 && blockIdx.x == 0) resident_exit(p.exit_word, 2u, served, scan_ticks);
+            return;
+        }
+        const uint64_t t_seen = blockIdx.x == 0 ? __builtin_amdgcn_s_memrealtime() : 0;
+        if (cmd == 1u) {
+            if (tid == 0 && blockIdx.x == 0) resident_exit(p.exit_word, 1u, served, scan_ticks);
+            return;
+        }
+        // ---- the entry lines (one chunk), each verified by its tag
+        bool torn = false;
+        if (lines > 1) {
+            const int chunk = lines - 1;
+            const bool staged = chunk == 1 && line1_staged;
+            for (int base = 0; base < chunk * 4 && !staged; base += nt) {
+                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                const int c = base + tid;
+                if (c < chunk * 4) {
+                    const int line = 1 + (c >> 2);
+                    const uint32_t *src = line == 1 ? my_unit + 16 + (c & 3) * 4 : p.mailbox + (kMailboxTail + (size_t)(line - 2) * 16 + (c & 3) * 4);
+                    v4u x;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x) : "v"(src) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)::"memory");
+                    *reinterpret_cast<v4u *>(lm + 16 + c * 4) = x;
+                }
+            }
+            __syncthreads();
+            int bad = 0;
+            for (int l = tid; l < chunk; l += nt) bad |= (lm[(1 + l) * 16 + 15] != seq);
+            torn = __syncthreads_or(bad) != 0;
+        }
+        if (torn) continue;                                    // a line was still in flight: poll again (nothing has been applied yet)
+        // ---- moved nodes: {node, delta}; entry 0 rides in the header
+        for (int i = tid; i < n_pi; i += nt) {
+            uint32_t node, lo, hi;
+            if (i == 0) { node = p0_node; lo = p0_lo; hi = p0_hi; }
+            else { const uint32_t *q = lm + (1 + (i - 1) / kMailboxPatchesPerLine) * 16 + 3 * ((i - 1) % kMailboxPatchesPerLine); node = q[0]; lo = q[1]; hi = q[2]; }
+            const int a0 = p.adj_start[node], a1 = p.adj_start[node + 1];
+            s_node[i] = (int)node;
+            s_delta[i] = (int64_t)(((uint64_t)hi << 32) | lo);
+            s_lo[i] = a0;
+            s_pre[i + 1] = a1 - a0;
+        }
+        if (tid == 0) s_pre[0] = 0;
+        __syncthreads();
+        if (n_pi > 0) {
+            // inclusive scan of the list lengths (Hillis-Steele over at most kNodesMax entries; every thread owns up to two)
+            for (int off = 1; off < n_pi; off <<= 1) {
+                int v0 = 0, v1 = 0;
+                const int i0 = tid + 1, i1 = tid + 1 + nt;
+                if (i0 <= n_pi && i0 - off >= 1) v0 = s_pre[i0 - off];
+                if (i1 <= n_pi && i1 - off >= 1) v1 = s_pre[i1 - off];
+                __syncthreads();
+                if (i0 <= n_pi) s_pre[i0] += v0;
+                if (i1 <= n_pi) s_pre[i1] += v1;
+                __syncthreads();
+            }
+            const int total = s_pre[n_pi];
+            for (int f = tid; f < total; f += nt) {
+                int k = 0;
+                for (int step = 1024; step > 0; step >>= 1)           // largest k < n_pi with s_pre[k] <= f
+                    if (k + step < n_pi && s_pre[k + step] <= f) k += step;
+                const uint32_t x = p.adj[s_lo[k] + (f - s_pre[k])];
+                const int pos = (int)(x & 0x7FFFFFFFu);
+                const bool mine = LD ? (pos >= w_lo && pos < w_lo + p.window) : ((int)(((uint32_t)pos / (uint32_t)(nt * kArcsPerThread)) % gridDim.x) == (int)blockIdx.x);
+                if (mine) {
+                    const long long add = (x >> 31) ? -s_delta[k] : s_delta[k];
+                    atomicAdd(reinterpret_cast<unsigned long long *>(p.rc + pos), (unsigned long long)add);
+                    if (LD) atomicAdd(reinterpret_cast<unsigned long long *>(ld + (pos - w_lo)), (unsigned long long)add);
+                }
+            }
+            if (blockIdx.x == 0) {
+                for (int i = tid; i < n_pi; i += nt) {
+                    if (p.narrow) reinterpret_cast<int32_t *>(p.pi)[s_node[i]] += (int32_t)s_delta[i];
+                    else reinterpret_cast<int64_t *>(p.pi)[s_node[i]] += s_delta[i];
+                }
+            }
+        }
+        // ---- State[] writes: final values (memory: every workgroup, idempotent; LDS copy: the window's owner)
+        for (int i = tid; i < n_st; i += nt) {
+            int arc; uint32_t val;
+            if (i == 0) { arc = st_arc0; val = st_val0; }
+            else if (i == 1) { arc = st_arc1; val = st_val1; }
+            else { const int j = extra_pi + (i - 2); const uint32_t *q = lm + (1 + j / kMailboxPatchesPerLine) * 16 + 3 * (j % kMailboxPatchesPerLine); arc = (int)q[0]; val = q[1]; }
+            const int a = arc - p.base;
+            if ((unsigned)a < (unsigned)p.count_padded) {
+                p.state[a] = (int8_t)val;
+                if (LD && a >= w_lo && a < w_lo + p.window) ls[a - w_lo] = (int8_t)val;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        // The shifts above are atomics performed in this XCD's L2; a line of d that this CU's L1 still holds from an earlier request would be
+        // stale.  Only the L1 has to forget it (buffer_inv sc0: the L1 alone -- an agent-scope invalidate also walks the L2 and cost 30 us
+        // per request when every wave issued one).  The LDS variant never reads d from memory again.
+        if (!LD && n_pi) asm volatile("buffer_inv sc0\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        // ---- scan
+        Key best;
+        best.c = 0;
+        best.r = kNone;
+        best.p = kNone;
+        if (LD) {
+            for (int i = tid * kArcsPerThread; i < p.window; i += nt * kArcsPerThread) {
+                const uint32_t st4 = *reinterpret_cast<const uint32_t *>(ls + i);
+                const int64_t d[4] = {ld[i], ld[i + 1], ld[i + 2], ld[i + 3]};
+                fold_rc<RULE, OPT>(st4, d, p.base + w_lo + i, p.m_s, next_arc, block_size, rstar, best);
+            }
+        } else {
+            typedef long v2l __attribute__((ext_vector_type(2)));
+            const int step = gridDim.x * nt * kArcsPerThread;
+            for (int i0 = blockIdx.x * nt * kArcsPerThread + tid * kArcsPerThread; i0 < p.count_padded; i0 += step) {
+                const uint32_t st4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p.state + i0));
+                const v2l a = __builtin_nontemporal_load(reinterpret_cast<const v2l *>(p.rc + i0));
+                const v2l b = __builtin_nontemporal_load(reinterpret_cast<const v2l *>(p.rc + i0 + 2));
+                const int64_t d[4] = {a.x, a.y, b.x, b.y};
+                fold_rc<RULE, OPT>(st4, d, p.base + i0, p.m_s, next_arc, block_size, rstar, best);
+            }
+        }
+        publish_best<RULE, true, kResidentThreads>(best, p.slots + (size_t)blockIdx.x * kSlotStride, seq, true);
+        last = seq;
+        served += 1;
+        idle_since = __builtin_amdgcn_s_memrealtime();
+        if (blockIdx.x == 0) scan_ticks += idle_since - t_seen;
+        __syncthreads();
+    }
+}
+
 // pi[node[i]] = value[i], state[arc[j]] = s[j]; lists read straight from pinned host memory
 template <typename T>
 __global__ __launch_bounds__(kThreads) void update_kernel(T *pi, const int32_t *nodes, const int64_t *values, int n_pi,

@@ -754,7 +754,9 @@ int mcf_ns_prepare(mcf_ns *s)
             const int sharing = (int)std::count(s->group_devices.begin(), s->group_devices.end(), dr.device);
             if (sharing > 1) {                       // shards rehearsed on one GPU: every grid must fit beside the others
                 dr.flags |= MCF_ENGINE_SHARE_DEVICE;
-                dr.resident_workgroups = std::max(1, 256 / sharing);
+                // workgroups go to the 8 XCDs (32 CUs each) round-robin: an even share per XCD, or one XCD ends up with more 1024-thread
+                // workgroups than CUs and a grid never becomes fully resident
+                dr.resident_workgroups = std::max(8, 32 / sharing * 8);
                 if (sharing > 3) dr.flags |= MCF_ENGINE_DISPATCH;      // more grids than the device has hardware queues for this process (engine.hip: resident slots)
             }
         }

@@ -36,15 +36,19 @@ def _oracle_scan(rule, optimized, a, m_s, block, next_arc):
 MODES = [pytest.param(M.ENGINE_NO_CANDIDATES, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"), pytest.param(0, id="candidates"),
          pytest.param(M.ENGINE_SHARE_DEVICE | M.ENGINE_NO_CANDIDATES, id="resident-shared"),      # resident grid without register-resident potentials
          pytest.param(M.ENGINE_SHARE_DEVICE, id="candidates-shared"),
-         pytest.param("rc", id="rc-layout")]      # reduced costs kept per arc (what large sparse instances use), forced onto these sizes
+         # reduced costs kept per arc (what large sparse instances use), forced onto these sizes: one dispatch per search, the resident grid
+         # with the arcs in LDS, and the resident grid streaming them from memory
+         pytest.param("rc", id="rc-layout"), pytest.param("rc-resident", id="rc-resident-lds"), pytest.param("rc-stream", id="rc-resident-stream")]
 CAND_MODES = (0, M.ENGINE_SHARE_DEVICE)
 
 
 def _mode_flags(mode, monkeypatch):
-    """Engine flags of a MODES entry; "rc" = one dispatch per search over the RC layout (MCF_HIP_RC=1 forces it on any size)."""
-    if mode == "rc":
+    """Engine flags of a MODES entry; the "rc*" entries force the RC layout (MCF_HIP_RC=1) onto any size."""
+    if isinstance(mode, str):
         monkeypatch.setenv("MCF_HIP_RC", "1")
-        return M.ENGINE_DISPATCH
+        if mode == "rc-stream":
+            monkeypatch.setenv("MCF_HIP_RC_LDS", "0")
+        return M.ENGINE_DISPATCH if mode == "rc" else 0
     return mode
 
 
@@ -54,7 +58,8 @@ def _mode_flags(mode, monkeypatch):
 def test_scan_matches_oracle_on_random_arrays(width, rule, optimized, mode, monkeypatch):
     """Ragged sizes, heavy ties (tiny cost range), random patches between searches (short lists, long lists), in both
     engine modes: the resident grid fed through the mailbox and one dispatch per search."""
-    rc_layout = mode == "rc"
+    rc_layout = isinstance(mode, str)
+    rc_resident = rc_layout and mode != "rc"
     mode = _mode_flags(mode, monkeypatch)
     rng = np.random.default_rng(1234 + width + 10 * rule + optimized)
     for m_s, n, span in [(1, 2, 3), (3, 2, 2), (4, 5, 2), (5, 3, 50), (1023, 40, 3), (1024, 300, 2), (1025, 7, 10 ** 6),
@@ -98,11 +103,13 @@ def test_scan_matches_oracle_on_random_arrays(width, rule, optimized, mode, monk
         assert st["searches"] == 12 and st["resident"] == (0 if mode == M.ENGINE_DISPATCH else 1)
         if mode not in CAND_MODES:
             assert st["candidates"] == 0
-        if rc_layout:
+        if rc_resident:
+            assert st["rc_layout"] == 1 and st["resident"] == 1 and st["resident_requests"] >= 12 and st["scan_bytes_read"] == 9 * m_s
+        elif rc_layout:
             assert st["rc_layout"] == 1 and (st["update_launches"] > 0 or n < 100) and st["inline_updates"] > 0 and st["scan_bytes_read"] == 9 * m_s
         elif mode == M.ENGINE_DISPATCH:
             assert (st["inline_updates"] > 0 and st["update_launches"] > 0) or n < 97
-        elif mode in CAND_MODES and rule == O.RULE_BEST and m_s <= 1 << 20 and 2 * m_s <= 24 * n:
+        elif not rc_layout and mode in CAND_MODES and rule == O.RULE_BEST and m_s <= 1 << 20 and 2 * m_s <= 24 * n:
             assert st["candidates"] == 1 and st["resident_requests"] + st["host_decided"] >= 12
         else:
             assert st["resident_requests"] >= 12 and st["update_launches"] <= 1    # the patches queued after the last search
@@ -164,7 +171,8 @@ def _solve_both(p, sem, rule, int_width=0, flags=0, supply_type=O.GEQ, block_siz
                                   "SimpleProblemIllustration2NonSparse", "AURV19V6", "grid_5x5", "star_graph"])
 def test_solve_is_pivot_for_pivot_identical(name, mode, monkeypatch):
     """Same entering arc at every pivot, hence same flows and potentials, for both C# flavours of every rule."""
-    rc_layout = mode == "rc"
+    rc_layout = isinstance(mode, str)
+    rc_resident = rc_layout and mode != "rc"
     mode = _mode_flags(mode, monkeypatch)
     p = load(name)
     for sem, rule in [(O.SEM_CSHARP_OPT, O.RULE_BLOCK), (O.SEM_CSHARP, O.RULE_BLOCK), (O.SEM_CSHARP_OPT, O.RULE_BEST),
@@ -189,7 +197,7 @@ def test_solve_is_pivot_for_pivot_identical(name, mode, monkeypatch):
         else:
             assert (m["initial_block_size"], m["final_block_size"], m["total_arcs_checked"]) == (0, 0, 0)
         assert m["engine"]["resident"] == (0 if mode == M.ENGINE_DISPATCH else 1)
-        if mode in CAND_MODES and rule == O.RULE_BEST and 2 * o.search_arc_num <= 24 * (p.n + 1):
+        if not rc_layout and mode in CAND_MODES and rule == O.RULE_BEST and 2 * o.search_arc_num <= 24 * (p.n + 1):
             assert m["engine"]["candidates"] == 1 and m["engine"]["host_decided"] + m["engine"]["resident_requests"] >= o.n_pivots
 
 
@@ -579,7 +587,8 @@ def test_register_resident_potentials_pivot_for_pivot():
 def test_potential_lists_that_arrive_in_pieces(mode, m_s, n, monkeypatch):
     """mcf_engine_append_potential: the list of one pivot handed over in several calls (disjoint nodes); in resident mode the complete lines
     travel at once (apply posts) and the search finishes the list.  Every engine mode, potentials in registers / LDS / memory."""
-    rc_layout = mode == "rc"
+    rc_layout = isinstance(mode, str)
+    rc_resident = rc_layout and mode != "rc"
     mode = _mode_flags(mode, monkeypatch)
     rng = np.random.default_rng(31 + m_s)
     a = _random_soa(rng, m_s, n, 3, 9)
@@ -607,7 +616,8 @@ def test_potential_lists_that_arrive_in_pieces(mode, m_s, n, monkeypatch):
 def test_search_in_two_halves(mode, monkeypatch):
     """mcf_engine_search_begin / _end: the answer is the blocking call's; patches queued while a search is in flight belong to the next one;
     parking the engine (or reading its statistics) in between keeps the answer."""
-    rc_layout = mode == "rc"
+    rc_layout = isinstance(mode, str)
+    rc_resident = rc_layout and mode != "rc"
     mode = _mode_flags(mode, monkeypatch)
     rng = np.random.default_rng(606)
     m_s, n = 120007, 30000
@@ -641,7 +651,7 @@ def test_search_in_two_halves(mode, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [pytest.param(M.ENGINE_NO_CANDIDATES, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"),
                                   pytest.param(M.ENGINE_SHARE_DEVICE | M.ENGINE_NO_CANDIDATES, id="resident-shared"), pytest.param(0, id="candidates"),
-                                  pytest.param("rc", id="rc-layout")])
+                                  pytest.param("rc", id="rc-layout"), pytest.param("rc-resident", id="rc-resident-lds"), pytest.param("rc-stream", id="rc-resident-stream")])
 @pytest.mark.parametrize("m_s,n", [(400003, 100001), (60001, 16000)])
 def test_state_patch_lists_of_any_length(mode, m_s, n, monkeypatch):
     """mcf_engine_patch_state with 65, 200 and 5000 distinct arcs between two searches, each time with a potential list pending
@@ -805,7 +815,7 @@ CONFIG5 = (13502460, 1_000_000, 8_000_000, 1000, 1000)
 @pytest.mark.gpu
 def test_config5_solves_end_to_end_and_shards_follow_the_same_pivots():
     """BASELINE.json configs[4] on ONE GPU, end to end: NETGEN-like 1M nodes / 8M arcs, Best Eligible, int64, through mcf_ns_solve with
-    the layout the engine picks by itself at this size (reduced costs kept per arc, one dispatch per search, 1024 records per search).  Checked by
+    the layout the engine picks by itself at this size (reduced costs kept per arc, streamed by a resident grid of 256 workgroups).  Checked by
       * the device validator's optimality certificate (mcf_ns_validate: conservation, bounds, complementary slackness, primal = dual),
       * the optimal cost of the CPU oracle's Block-Search solve of the same instance (tests/golden/config5_cost.json; 15-20 CPU minutes,
         hence golden -- generated by tests/golden/make_config5_cost.py),
@@ -822,7 +832,7 @@ def test_config5_solves_end_to_end_and_shards_follow_the_same_pivots():
     assert ns.solve() == M.SolverStatus.Optimal
     m = ns.get_metrics()
     assert m["search_arc_num"] == gold["search_arc_num"] == 9_000_000 and m["iterations"] > 1_000_000
-    assert m["engine"]["resident"] == 0 and m["engine"]["rc_layout"] == 1 and m["engine"]["scan_workgroups"] == 1024    # what the engine chooses at this size
+    assert m["engine"]["resident"] == 1 and m["engine"]["rc_layout"] == 1 and m["engine"]["scan_workgroups"] == 256     # what the engine chooses at this size
     cost = ns.get_total_cost()
     assert cost == gold["total_cost"], (cost, gold["total_cost"])
     v = ns.validate()
@@ -849,7 +859,7 @@ def test_config5_solves_end_to_end_and_shards_follow_the_same_pivots():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [pytest.param(M.ENGINE_NO_CANDIDATES, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"), pytest.param(0, id="candidates-or-default"),
-                                  pytest.param("rc", id="rc-layout")])
+                                  pytest.param("rc", id="rc-layout"), pytest.param("rc-resident", id="rc-resident-lds"), pytest.param("rc-stream", id="rc-resident-stream")])
 def test_patch_arcs_rewrites_end_points_and_costs(mode, monkeypatch):
     """mcf_engine_patch_arcs (artificial arcs re-pointed by a warm start): source / target / cost of some arcs change between two searches;
     in the RC layout the per-arc reduced costs and the nodes' arc lists are rebuilt.  The candidate cache refuses (its mirrors are fixed)."""
