@@ -262,6 +262,25 @@ def large_instance_sample(M, local_rank, with_cpu, gpu_pivots=3000, cpu_seconds=
         del nsg
     except M.McfError as err:
         out["as_8_shards_on_this_one_gpu"] = {"error": str(err)}
+    # what ONE of eight GPUs would do per pivot: an engine that holds the first eighth of the search arcs (1.125 M arcs: its windows of reduced
+    # costs live in LDS), one search after a one-node shift and two state writes, 2000 times -- the sharded pivot's device leg without the exchange
+    try:
+        import numpy as np
+        ns0 = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible)
+        assert ns0.begin() == 0
+        it0 = ns0.internal(); ms = it0["search_arc_num"]
+        eng = M.PivotEngine(g5.node_count + 1, ms, ms, rule=M.PivotRule.BestEligible, int_width=64, device=local_rank, shard=M.shard_range(ms, 0, 8))
+        eng.upload(it0["source"][:ms], it0["target"][:ms], it0["cost"][:ms], it0["state"][:ms], it0["pi"])
+        avg, mn = eng.bench_search(2000)
+        st = eng.stats()
+        out["one_eighth_shard_on_its_own_gpu"] = {"arcs": int(M.shard_range(ms, 0, 8)[1]), "searches": 2000, "us_per_search": avg / 1e3, "min_us": mn / 1e3,
+                                                  "resident": bool(st["resident"]), "rc_layout": bool(st["rc_layout"]), "workgroups": st["scan_workgroups"],
+                                                  "in_kernel_us_per_request": st["resident_scan_ns"] / max(st["resident_requests"], 1) / 1e3,
+                                                  "what": "device leg of a sharded pivot on an 8-GPU node (each GPU holds such a shard: windows of reduced costs in LDS): "
+                                                          "mailbox post -> scan -> 256 records merged on the host, no patches, no exchange (mcf_engine_bench_search)"}
+        del eng, ns0
+    except M.McfError as err:
+        out["one_eighth_shard_on_its_own_gpu"] = {"error": str(err)}
     if with_cpu:
         b = cpu_baseline(g5, M.PivotRule.BestEligible, cpu_seconds)
         out["cpu_port_same_rule"] = {"us_per_pivot": b["us_per_pivot"], "sample": b["sample"], "cores": 1}

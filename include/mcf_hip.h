@@ -268,6 +268,10 @@ MCF_API int mcf_engine_reset_stats(mcf_engine *e);
 MCF_API int mcf_engine_bench_scan(mcf_engine *e, int32_t reps, int32_t cold, int64_t flush_bytes,
                                   double *avg_ns, double *min_ns);
 
+/* Whole-search micro-benchmark: host wall time from posting / launching a search to its merged answer, `reps` times back to back without
+ * patches (the candidate cache is bypassed by nothing here: an engine with the cache answers from it).  avg/min in ns. */
+MCF_API int mcf_engine_bench_search(mcf_engine *e, int32_t reps, double *avg_ns, double *min_ns);
+
 /* RCCL exchange for sharded engines: one ncclAllGather of 16 bytes per rank per pivot on the engine's stream.
  * id_out/id: the 128-byte ncclUniqueId, created on rank 0 and broadcast by the caller (torch.distributed). */
 MCF_API int mcf_comm_unique_id(uint8_t id_out[128]);

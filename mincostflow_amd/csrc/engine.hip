@@ -2146,6 +2146,29 @@ int mcf_engine_bench_scan(mcf_engine *e, int32_t reps, int32_t cold, int64_t flu
     return MCF_OK;
 }
 
+// host wall time of a whole search (post / launch -> records merged) on the engine's resident arrays, `reps` times back to back without
+// patches: the round trip a pivot waits for.  Works on whole and on sharded engines; next_arc is left alone.
+int mcf_engine_bench_search(mcf_engine *e, int32_t reps, double *avg_ns, double *min_ns)
+{
+    if (!e || reps < 1 || !avg_ns || !min_ns) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_bench_search: bad arguments");
+    if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
+    HIP_TRY(hipSetDevice(e->d.device));
+    Key k;
+    for (int r = 0; r < 16; ++r) { const int rc = local_search(e, &k); if (rc) return rc; }      // the grid is up, the caches are warm
+    double sum = 0, mn = 1e30;
+    for (int r = 0; r < reps; ++r) {
+        const double t0 = mcf::now_ns();
+        const int rc = local_search(e, &k);
+        if (rc) return rc;
+        const double dt = mcf::now_ns() - t0;
+        sum += dt;
+        mn = std::min(mn, dt);
+    }
+    *avg_ns = sum / reps;
+    *min_ns = mn;
+    return MCF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ RCCL exchange
 
 int mcf_comm_unique_id(uint8_t id_out[128])

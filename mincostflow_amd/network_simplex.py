@@ -469,6 +469,15 @@ class HostExchange:
         self.close()
 
 
+def _bench_search(self, reps=1000):
+    avg, mn = C.c_double(), C.c_double()
+    L.check(L.lib().mcf_engine_bench_search(self._h, reps, C.byref(avg), C.byref(mn)))
+    return avg.value, mn.value
+
+
+PivotEngine.bench_search = _bench_search
+
+
 def shard_range(search_arc_num: int, rank: int, world: int):
     b, e = C.c_int32(), C.c_int32()
     L.check(L.lib().mcf_shard_range(search_arc_num, rank, world, C.byref(b), C.byref(e)))
