@@ -239,8 +239,9 @@ def large_instance_sample(M, local_rank, with_cpu, gpu_pivots=3000, cpu_seconds=
     RC layout, one dispatch per search).  Same-rule CPU port on the same first pivots beside it."""
     g5 = M.netgen_like(SEED, 1_000_000, 8_000_000, 1000, 1000)
     ns = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True)
-    ns.set_device(local_rank, 64, 0, 0).set_pivot_limit(gpu_pivots).prepare()
+    ns.set_device(local_rank, 64, 0, 0).set_pivot_limit(gpu_pivots).record_trace(gpu_pivots).prepare()
     ns.solve()
+    gpu_trace = ns.trace()
     m = ns.get_metrics(); it = max(m["iterations"], 1)
     out = {"workload": "NETGEN-like 1M nodes / 8M arcs (config 5 on one GPU), Best Eligible, int64, first pivots only", "pivots": m["iterations"],
            "us_per_pivot": m["loop_us"] / it, "pivot_search_us": m["pivot_search_us"] / it, "pivots_per_s": it / (m["loop_us"] / 1e6),
@@ -285,6 +286,20 @@ def large_instance_sample(M, local_rank, with_cpu, gpu_pivots=3000, cpu_seconds=
         b = cpu_baseline(g5, M.PivotRule.BestEligible, cpu_seconds)
         out["cpu_port_same_rule"] = {"us_per_pivot": b["us_per_pivot"], "sample": b["sample"], "cores": 1}
         out["gpu_over_cpu_per_pivot"] = b["us_per_pivot"] / out["us_per_pivot"]
+        # the sampled pivots are the CPU port's pivots: its first entering arcs against the GPU run's trace
+        from oracle import ns_oracle as O
+        p5 = O.Problem(g5.node_count, g5.arc_count, g5.source, g5.target, g5.lower, g5.upper, g5.cost, g5.supply)
+        o = O.Oracle(p5, O.SEM_CSHARP_OPT, O.RULE_BEST)
+        o.init()
+        same = 0
+        for k in range(min(150, len(gpu_trace))):
+            f, e = o.find_entering()
+            if not f or e != int(gpu_trace[k]):
+                break
+            o.apply_pivot(e)
+            same += 1
+        out["pivots_identical_to_cpu_port"] = {"checked": min(150, len(gpu_trace)), "identical": same}
+        assert same == min(150, len(gpu_trace)), "the GPU run's pivots differ from the CPU port's"
     return out
 
 
@@ -584,6 +599,19 @@ def main():
     if not args.no_microbench and args.gpus == 1:
         line["scan_microbench"] = microbench()
         line["hbm_measured"] = hbm_probe()
+        c5 = [x for x in line["scan_microbench"] if x["case"].startswith("NETGEN-like 1M nodes / 8M arcs start basis")]
+        if c5:
+            # the kernel of this build that IS bandwidth-bound: the RC layout's scan over config 5's arrays (the roofline above is a latency figure)
+            x = c5[0]
+            tr = None
+            if os.path.exists(tpath):
+                tr = json.load(open(tpath)).get("scan_rc_config5", {}).get("hbm_bytes_per_scan")
+            line["roofline"]["bandwidth_bound_kernel"] = {
+                "kernel": "scan_rc_kernel<BestEligible> over NETGEN-like 1M nodes / 8M arcs (BASELINE config 5's arrays)", "bound": "hbm",
+                "bytes_per_launch": x["bytes"], "what_the_bytes_are": "9 B per arc: state + the arc's reduced cost (this layout's scan reads nothing else; SURVEY.md 8d's 17 B per arc + potentials would be " + str(x["survey_bytes"]) + ")",
+                "avg_launch_us_cold": x["cold_us"], "avg_launch_us_warm": x["warm_us"], "achieved": x["cold_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": x["cold_frac_of_hbm_peak"], "frac_warm": x["warm_frac_of_hbm_peak"], "traffic": tr,
+                "traffic_source": f"profiles/{TRAFFIC_FILE} (separate rocprofv3 --pmc FETCH_SIZE pass)" if tr else None}
     if not args.no_microbench and args.gpus == 1:
         line["large_instance_sample"] = large_instance_sample(M, local_rank, not args.no_cpu_baseline)
     if not args.no_validator and args.gpus == 1:

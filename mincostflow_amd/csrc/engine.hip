@@ -96,6 +96,8 @@ struct mcf_engine {
     void *d_cost = nullptr, *d_pi = nullptr;
     int8_t *d_state = nullptr;
     Slot *h_slots = nullptr, *d_slots = nullptr;    // pinned host memory and its device alias
+    Slot *d_dev_slots = nullptr;                    // the same records in device memory (RCCL exchange: they are folded on the device)
+    Slot *slots_target = nullptr;                   // where the next dispatch writes its records
     int grid = 0, unroll = 1;
     bool nt = false;
     bool lds_pi = false;           // node_count <= kLdsPiMax: kernels keep the potentials in LDS
@@ -231,7 +233,7 @@ void fill_params(mcf_engine *e, ScanParams<T> &p, bool with_patches)
     p.cost = (const T *)e->d_cost;
     p.state = e->d_state;
     p.pi = (T *)e->d_pi;
-    p.slots = e->d_slots;
+    p.slots = e->slots_target ? e->slots_target : e->d_slots;
     p.orig = e->bucket_nodes > 0 ? e->d_orig : nullptr;
     p.base = e->begin;
     p.count_padded = e->count_padded;
@@ -324,7 +326,7 @@ int launch_scan(mcf_engine *e, bool with_patches, bool timed)
 
 void fill_rc_params(mcf_engine *e, RcParams &p, bool with_states)
 {
-    p.state_ro = e->d_state; p.state = e->d_state; p.rc = e->d_rc; p.slots = e->d_slots;
+    p.state_ro = e->d_state; p.state = e->d_state; p.rc = e->d_rc; p.slots = e->slots_target ? e->slots_target : e->d_slots;
     p.base = e->begin; p.count_padded = e->count_padded; p.m_s = e->d.search_arc_num;
     p.next_arc = e->next_arc >= e->d.search_arc_num ? 0 : e->next_arc;
     p.block_size = e->block_size;
@@ -1620,7 +1622,7 @@ void mcf_engine_destroy(mcf_engine *e)
     if (e->d_orig) (void)hipFree(e->d_orig);
     (void)hipFree(e->d_rc); (void)hipFree(e->d_adj_start); (void)hipFree(e->d_adj);
     (void)hipFree(e->d_src); (void)hipFree(e->d_tgt); (void)hipFree(e->d_cost); (void)hipFree(e->d_state); (void)hipFree(e->d_pi);
-    (void)hipFree(e->d_cand_local); (void)hipFree(e->d_cand_all); (void)hipFree(e->d_flush);
+    (void)hipFree(e->d_cand_local); (void)hipFree(e->d_cand_all); (void)hipFree(e->d_flush); (void)hipFree(e->d_dev_slots);
     if (e->h_cand_all) (void)hipHostFree(e->h_cand_all);
     if (e->h_slots) (void)hipHostFree(e->h_slots);
     for (auto &s : e->stage) {
@@ -2190,8 +2192,13 @@ int mcf_engine_comm_init(mcf_engine *e, const uint8_t id[128], int32_t rank, int
     HIP_TRY(hipSetDevice(e->d.device));
     // the all-gather runs on the engine's stream between the scans: one dispatch per search from here on
     if (int rcs = resident_stop(e)) return rcs;
+    if (e->in_flight != mcf_engine::kNoSearch) return mcf::fail(MCF_ERR_STATE, "mcf_engine_comm_init: a search is in flight");
+    if (e->cand_on) {              // the candidate cache lives on the resident grid's answers: hand what it still holds to the device and switch it off
+        if (int rcf = flush_pending(e)) return rcf;
+        e->cand_on = false;
+        e->st.candidates = 0;
+    }
     if (e->resident_ok) {
-        if (e->in_flight != mcf_engine::kNoSearch) return mcf::fail(MCF_ERR_STATE, "mcf_engine_comm_init: a search is in flight");
         e->resident_ok = false;
         e->st.resident = 0;
         e->st.scan_workgroups = e->grid;
@@ -2207,6 +2214,7 @@ int mcf_engine_comm_init(mcf_engine *e, const uint8_t id[128], int32_t rank, int
     if (r->comm_count) { int seen = 0; if (r->comm_count(e->comm, &seen) == 0) e->st.comm_ranks = seen; }     // as the communicator itself reports it
     HIP_TRY(hipMalloc((void **)&e->d_cand_local, sizeof(mcf_candidate)));
     HIP_TRY(hipMalloc((void **)&e->d_cand_all, sizeof(mcf_candidate) * world));
+    HIP_TRY(hipMalloc((void **)&e->d_dev_slots, sizeof(Slot) * kMaxWorkgroups * kSlotStride));
     HIP_TRY(hipHostMalloc((void **)&e->h_cand_all, sizeof(mcf_candidate) * world, hipHostMallocDefault));
     return MCF_OK;
 }
@@ -2215,11 +2223,31 @@ int mcf_engine_find_entering_sharded(mcf_engine *e, int32_t *found, int32_t *arc
 {
     if (!e || !found || !arc) return mcf::fail(MCF_ERR_INVALID, "null argument");
     if (!e->comm) return mcf::fail(MCF_ERR_STATE, "mcf_engine_comm_init has not been called");
-    mcf_candidate mine;
-    int rc = mcf_engine_find_entering_local(e, &mine);
+    HIP_TRY(hipSetDevice(e->d.device));
+    // the scan writes its per-workgroup records into device memory and one more workgroup folds them into the all-gather's send buffer:
+    // no host poll and no 16-byte copy to the device between the scan and the collective
+    e->slots_target = e->d_dev_slots;
+    int rc = search_begin(e);                // one dispatch (comm_init took the engine out of resident mode), patches as usual
+    e->slots_target = nullptr;
     if (rc) return rc;
+    if (e->in_flight != mcf_engine::kDispatchSearch) return mcf::fail(MCF_ERR_STATE, "sharded search did not dispatch");
+    e->in_flight = mcf_engine::kNoSearch;    // nothing will be collected from the host records
+    {
+        const int na = e->next_arc >= e->d.search_arc_num ? 0 : e->next_arc;
+        int rstar = -1;
+        if (e->d.rule == MCF_RULE_BLOCK_SEARCH && e->d.semantics == MCF_SEM_OPTIMIZED && e->next_arc < e->d.search_arc_num) {
+            const int len1 = e->d.search_arc_num - e->next_arc;
+            if (len1 % e->block_size) rstar = len1 / e->block_size;
+        }
+        const dim3 one(1), block(kThreads);
+        switch (e->d.rule) {
+        case MCF_RULE_BEST_ELIGIBLE: hipLaunchKernelGGL(reduce_records_kernel<MCF_RULE_BEST_ELIGIBLE>, one, block, 0, e->stream, e->d_dev_slots, e->grid, e->d.search_arc_num, na, e->next_arc, e->block_size, rstar, e->d_cand_local); break;
+        case MCF_RULE_FIRST_ELIGIBLE: hipLaunchKernelGGL(reduce_records_kernel<MCF_RULE_FIRST_ELIGIBLE>, one, block, 0, e->stream, e->d_dev_slots, e->grid, e->d.search_arc_num, na, e->next_arc, e->block_size, rstar, e->d_cand_local); break;
+        default: hipLaunchKernelGGL(reduce_records_kernel<MCF_RULE_BLOCK_SEARCH>, one, block, 0, e->stream, e->d_dev_slots, e->grid, e->d.search_arc_num, na, e->next_arc, e->block_size, rstar, e->d_cand_local);
+        }
+        HIP_TRY(hipGetLastError());
+    }
     // MINLOC over (key, arc): RCCL has no MINLOC, so all-gather the 16-byte records and reduce locally
-    HIP_TRY(hipMemcpyAsync(e->d_cand_local, &mine, sizeof(mine), hipMemcpyHostToDevice, e->stream));
     const int nrc = rccl()->all_gather(e->d_cand_local, e->d_cand_all, sizeof(mcf_candidate), kNcclChar, e->comm, e->stream);
     if (nrc != 0) return mcf::fail(MCF_ERR_COMM, "ncclAllGather: %s", rccl()->error_string ? rccl()->error_string(nrc) : "error");
     HIP_TRY(hipMemcpyAsync(e->h_cand_all, e->d_cand_all, sizeof(mcf_candidate) * e->world, hipMemcpyDeviceToHost, e->stream));

@@ -1141,6 +1141,50 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
     }
 }
 
+// The RCCL exchange of sharded engines wants this shard's candidate in DEVICE memory (the all-gather's send buffer): one workgroup folds the
+// scan's per-workgroup records -- written to device memory in that mode -- with the rule's ordering, exactly as the host's collect() does.
+template <int RULE>
+__global__ __launch_bounds__(kThreads) void reduce_records_kernel(const Slot *slots, int grid, int m_s, int na, int next_arc, int block_size, int rstar, mcf_candidate *out)
+{
+    const int tid = threadIdx.x;
+    Key best;
+    best.c = 0;
+    best.r = kNone;
+    best.p = kNone;
+    for (int g = tid; g < grid; g += kThreads) {
+        const Slot s = slots[(size_t)g * kSlotStride];
+        if (s.p == kNone) continue;
+        uint32_t r = 0;
+        if (RULE == MCF_RULE_BLOCK_SEARCH) {
+            r = s.p / (uint32_t)block_size;
+            const int arc = (int)(((uint64_t)s.p + (uint32_t)na) % (uint32_t)m_s);
+            r = 2 * r + ((rstar >= 0 && (int)r == rstar && arc < next_arc) ? 1u : 0u);
+        }
+        if (best.p == kNone) { best.c = s.c; best.r = r; best.p = s.p; }
+        else take_if_better<RULE>(best, s.c, r, s.p);
+    }
+    // "none" must lose against every record: give it the largest key of the rule's ordering before the butterflies
+    if (best.p == kNone) { best.c = INT64_MAX; best.r = kNone; }
+    best = wave_min<RULE>(best);
+    __shared__ Key wave_best[kThreads / 64];
+    if ((tid & 63) == 0) wave_best[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        Key k = wave_best[0];
+        for (int w = 1; w < kThreads / 64; ++w) {
+            const Key o = wave_best[w];
+            if (o.p == kNone) continue;
+            if (k.p == kNone) k = o;
+            else take_if_better<RULE>(k, o.c, o.r, o.p);
+        }
+        mcf_candidate c;
+        c.reduced_cost = k.p == kNone ? 0 : k.c;
+        c.pos = k.p;
+        c.arc = k.p == kNone ? -1 : (RULE == MCF_RULE_BEST_ELIGIBLE ? (int32_t)k.p : (int32_t)(((uint64_t)k.p + (uint32_t)na) % (uint32_t)m_s));
+        *out = c;
+    }
+}
+
 // pi[node[i]] = value[i], state[arc[j]] = s[j]; lists read straight from pinned host memory
 template <typename T>
 __global__ __launch_bounds__(kThreads) void update_kernel(T *pi, const int32_t *nodes, const int64_t *values, int n_pi,

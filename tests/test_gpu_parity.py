@@ -335,19 +335,31 @@ def test_sharded_engines_resolve_like_one_engine(rule, optimized):
                 e.update_potential(nodes, -3)
 
 
-def test_sharded_solve_through_the_rccl_exchange():
-    """mcf_ns_set_sharding + mcf_engine_find_entering_sharded on the one GPU of this box (world size 1: the all-gather
-    and the MINLOC still run); more ranks are covered by tests/test_sharded_gloo.py and the same-device shard test above."""
-    p = load("netgen_8_10a")
-    for sem, rule in [(O.SEM_CSHARP_OPT, O.RULE_BEST), (O.SEM_CSHARP_OPT, O.RULE_BLOCK)]:
-        o = O.Oracle(p, sem, rule)
-        st_o, tr_o = o.solve(trace_cap=1 << 20)
+@pytest.mark.parametrize("layout", ["lds-potentials", "gathering", "rc"])
+def test_sharded_solve_through_the_rccl_exchange(layout, monkeypatch):
+    """mcf_ns_set_sharding + mcf_engine_find_entering_sharded on the one GPU of this box (world size 1: the scan's records are folded on the
+    device into the all-gather's send buffer, the all-gather and the MINLOC still run); more ranks are covered by tests/test_sharded_gloo.py
+    and the same-device shard tests.  Every rule, and each of the three dispatch kernels (potentials in LDS, gathered, RC layout)."""
+    if layout == "rc":
+        monkeypatch.setenv("MCF_HIP_RC", "1")
+    if layout == "lds-potentials":
+        p = load("netgen_8_10a")
+    else:
+        g = M.netgen_like(7, 20_000, 60_000, 100, 100)
+        p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
+    for sem, rule in [(O.SEM_CSHARP_OPT, O.RULE_BEST), (O.SEM_CSHARP_OPT, O.RULE_BLOCK), (O.SEM_CSHARP, O.RULE_BLOCK), (O.SEM_CSHARP_OPT, O.RULE_FIRST)]:
+        if layout != "lds-potentials" and rule == O.RULE_FIRST:
+            continue        # hundreds of thousands of pivots, nothing new
+        o = O.Oracle(p, sem, rule, auto_config=True)
+        st_o, tr_o = o.solve(trace_cap=1 << 22)
         ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
-        ns.set_pivot_rule(RULES[rule]).enable_optimized_pivot(True).record_trace(1 << 20)
+        ns.set_pivot_rule(RULES[rule]).enable_optimized_pivot(sem == O.SEM_CSHARP_OPT).record_trace(1 << 22)
         ns.set_sharding(M.comm_unique_id(), 0, 1)
         assert ns.solve() == st_o == 1
         assert np.array_equal(ns.trace(), tr_o) and ns.get_total_cost() == o.total_cost
-        assert ns.get_metrics()["engine"]["resident"] == 0         # sharded engines dispatch: the exchange needs the stream
+        e = ns.get_metrics()["engine"]
+        assert e["resident"] == 0 and e["comm_ranks"] == 1        # the exchange needs the stream: one dispatch per search
+        assert e["rc_layout"] == (1 if layout == "rc" else 0)
 
 
 def test_pivot_limit_stops_early():
