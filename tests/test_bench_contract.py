@@ -31,10 +31,14 @@ def _check(line, with_cpu):
         assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
 
 
-def test_committed_bench_line_keeps_the_contract():
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r01_bench_n1_final.json")).read().strip().splitlines()[-1])
+@pytest.mark.parametrize("name", ["r01_bench_n1_final.json", "r02_bench_n1.json"])
+def test_committed_bench_line_keeps_the_contract(name):
+    line = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
     _check(line, with_cpu=True)
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1
+    if name.startswith("r02"):
+        assert line["roofline"]["traffic_source"] and line["cpu_baseline"]["host_cpu"] and set(line["other_configs"]) == {"config2", "config4"}
+        assert line["engine"]["candidate_cache"] is True and line["every_search_on_the_device"]["identical_pivot_sequence"] is True
 
 
 @pytest.mark.gpu
