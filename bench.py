@@ -158,14 +158,6 @@ def sharded_leg(M, torch, dist, args, rank, world, dev, barrier, red_dev):
                                         "ranks": world, "pivots": m5["iterations"], "seconds": sec, "us_per_pivot": sec / max(m5["iterations"], 1) * 1e6,
                                         "pivots_per_s": m5["iterations"] / sec, "shard_engine_resident": bool(m5["engine"]["resident"])}
     same = True
-    if args.backend == "nccl":
-        ident = torch.from_numpy(M.comm_unique_id() if rank == 0 else np.zeros(128, "uint8")).cuda()
-        dist.broadcast(ident, src=0)
-        sec, m5, tr_rccl = run(lambda ns: ns.set_sharding(ident.cpu().numpy(), rank, world))
-        out["variants"]["rccl_all_gather"] = {"exchange": "ncclAllGather of 16 B per rank on the engine's stream + local MINLOC, every pivot",
-                                              "ranks": int(m5["engine"]["comm_ranks"]), "pivots": m5["iterations"], "seconds": sec,
-                                              "us_per_pivot": sec / max(m5["iterations"], 1) * 1e6, "pivots_per_s": m5["iterations"] / sec}
-        same = same and bool(np.array_equal(tr_rccl, tr_host))
     # the same pivots on ONE GPU (rank 0 alone, un-sharded), the figure the sharded ones have to beat
     if rank == 0:
         ns1 = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).set_device(dev, 64, 0, 0)
@@ -178,6 +170,29 @@ def sharded_leg(M, torch, dist, args, rank, world, dev, barrier, red_dev):
         same = same and bool(np.array_equal(ns1.trace(), tr_host))
         del ns1
     barrier()
+    if args.backend == "nccl":
+        # LAST, and under a watchdog: this is the one leg that no box of the builder's could run with more than one rank (one-GPU boxes), and a
+        # collective that never completes must not cost the whole line.  After a time-out the process group is left alone (no further collective).
+        import threading
+        box = {}
+
+        def rccl_leg():
+            ident = torch.from_numpy(M.comm_unique_id() if rank == 0 else np.zeros(128, "uint8")).cuda()
+            dist.broadcast(ident, src=0)
+            box["res"] = run(lambda ns: ns.set_sharding(ident.cpu().numpy(), rank, world))
+
+        th = threading.Thread(target=rccl_leg, daemon=True)
+        th.start()
+        th.join(timeout=180.0)
+        if "res" in box:
+            sec, m5, tr_rccl = box["res"]
+            out["variants"]["rccl_all_gather"] = {"exchange": "scan records folded on the device -> ncclAllGather of 16 B per rank on the engine's stream -> MINLOC on the host, every pivot",
+                                                  "ranks": int(m5["engine"]["comm_ranks"]), "pivots": m5["iterations"], "seconds": sec,
+                                                  "us_per_pivot": sec / max(m5["iterations"], 1) * 1e6, "pivots_per_s": m5["iterations"] / sec}
+            same = same and bool(np.array_equal(tr_rccl, tr_host))
+        else:
+            out["variants"]["rccl_all_gather"] = {"error": "did not finish within 180 s on this rank; the line was printed without it"}
+            out["abandon_process_group"] = True
     out["identical_pivot_sequence"] = same
     return out
 
@@ -469,7 +484,10 @@ def main():
     if dist is not None and args.sharded_pivots > 0:
         sharded = sharded_leg(M, torch, dist, args, rank, world, dev, barrier, red_dev)
 
+    abandon = bool(sharded and sharded.pop("abandon_process_group", False))
     if rank != 0:
+        if abandon:
+            os._exit(0)          # a collective of the RCCL leg never completed: nothing further can be synchronised
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -616,7 +634,9 @@ def main():
         line["large_instance_sample"] = large_instance_sample(M, local_rank, not args.no_cpu_baseline)
     if not args.no_validator and args.gpus == 1:
         line["solution_validator"] = validator_bench(M, g, solvers[0], local_rank, not args.no_cpu_baseline)
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
+    if abandon:
+        os._exit(0)
     if dist is not None:
         dist.destroy_process_group()
 

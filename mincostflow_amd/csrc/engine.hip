@@ -166,13 +166,13 @@ struct mcf_engine {
     std::vector<int32_t> h_src, h_tgt;            // host mirrors of the resident arrays (search arcs only)
     std::vector<int64_t> h_cost;
     std::vector<int8_t> h_state;
-    struct AdjEnt { int32_t arc; int32_t other; int64_t cost; };   // other: the arc's second end point, bit 31 set when THIS node is the arc's target
+    struct AdjEnt { int32_t arc; uint32_t other; int64_t cost; };  // other: the arc's second end point (bits 0-28), the arc's state + 1 (bits 29-30), bit 31 set when THIS node is the arc's target
     std::vector<int32_t> adj_start;
     std::vector<AdjEnt> adj;                      // arcs incident to each node, with what a re-evaluation needs next to each other
     // every change carries the number of the search it precedes ("epoch"); a snapshot taken at epoch P knows all changes stamped <= P
     std::vector<uint32_t> node_at, arc_at;        // epoch of the node's last potential change / the arc's last state change
     std::vector<uint32_t> arc_stamp;              // version of the arc's key; heap entries of an older version are stale
-    std::vector<uint32_t> arc_seen;               // == cand_now: already re-evaluated for this search
+    std::vector<int32_t> adj_pos;                 // where the two entries of an arc sit in adj (the second is -1 for a self loop): a state write reaches both
     uint32_t cand_now = 1;                        // epoch of the changes that are arriving
     uint32_t snap_at = 0;                         // epoch the candidate list reflects
     uint32_t heap_gap = 0;                        // latest epoch whose changes were NOT evaluated into the heap (a subtree too big to evaluate here)
@@ -189,6 +189,7 @@ struct mcf_engine {
     int blind_sets = 0;                           // lists in there that did not come as the continuation of another one
     bool cand_appending = false;                  // mcf_engine_append_potential is calling mcf_engine_set_potential
     std::vector<CandKey> cand_list;               // sorted; complete below cand_thr as of snap_at
+    std::vector<int32_t> cand_ends;               // the end points of the listed arcs (2 per entry), looked up once when the list is installed
     size_t cand_ptr = 0;
     CandKey cand_thr{0, 0xFFFFFFFFu};             // p == kNone: the list holds every eligible arc
     bool async_posted = false;                    // a refresh is on its way while the host keeps answering from the current list
@@ -956,8 +957,6 @@ inline int cand_note_nodes_blind(mcf_engine *e, int32_t count, const int32_t *no
 
 inline void cand_push(mcf_engine *e, int a)
 {
-    if (e->arc_seen[a] == e->cand_now) return;
-    e->arc_seen[a] = e->cand_now;
     const uint32_t stamp = ++e->arc_stamp[a];
     const int st = e->h_state[a];
     if (st == 0) return;
@@ -979,15 +978,15 @@ void cand_absorb_pivot(mcf_engine *e)
         const int64_t *pi = e->pi.data();
         for (int u : e->pivot_nodes) {
             const int64_t pu = pi[u];
+            // everything an evaluation needs sits in the entry except the other end's potential and the arc's version counter; an arc
+            // between two moved nodes is evaluated twice (the second entry outdates the first), which is cheaper than remembering it
             for (int i = e->adj_start[u], hi = e->adj_start[u + 1]; i < hi; ++i) {
                 const mcf_engine::AdjEnt &x = e->adj[i];
-                if (e->arc_seen[x.arc] == e->cand_now) continue;
-                e->arc_seen[x.arc] = e->cand_now;
                 const uint32_t stamp = ++e->arc_stamp[x.arc];
-                const int st = e->h_state[x.arc];
+                const int st = (int)((x.other >> 29) & 3u) - 1;
                 if (st == 0) continue;
-                const int64_t po = pi[x.other & 0x7FFFFFFF];
-                const int64_t d = x.other < 0 ? x.cost + po - pu : x.cost + pu - po;
+                const int64_t po = pi[x.other & 0x1FFFFFFFu];
+                const int64_t d = (x.other >> 31) ? x.cost + po - pu : x.cost + pu - po;
                 const int64_t rc = st > 0 ? d : -d;
                 if (rc >= 0) continue;
                 e->heap.push_back(mcf_engine::HeapEnt{rc, (uint32_t)x.arc, stamp});
@@ -1010,11 +1009,6 @@ void cand_absorb_pivot(mcf_engine *e)
     }
 }
 
-inline bool cand_entry_clean(const mcf_engine *e, uint32_t a)
-{
-    return e->arc_at[a] <= e->snap_at && e->node_at[e->h_src[a]] <= e->snap_at && e->node_at[e->h_tgt[a]] <= e->snap_at;
-}
-
 // true: *k holds the entering arc (or "none": the scan would find nothing either) without asking the device
 bool cand_decide(mcf_engine *e, Key *k)
 {
@@ -1033,7 +1027,11 @@ bool cand_decide(mcf_engine *e, Key *k)
         std::pop_heap(e->heap.begin(), e->heap.end(), CandHeapAfter());
         e->heap.pop_back();
     }
-    while (e->cand_ptr < e->cand_list.size() && !cand_entry_clean(e, e->cand_list[e->cand_ptr].p)) e->cand_ptr++;
+    while (e->cand_ptr < e->cand_list.size()) {
+        const uint32_t a = e->cand_list[e->cand_ptr].p;
+        if (e->arc_at[a] <= e->snap_at && e->node_at[e->cand_ends[2 * e->cand_ptr]] <= e->snap_at && e->node_at[e->cand_ends[2 * e->cand_ptr + 1]] <= e->snap_at) break;
+        e->cand_ptr++;
+    }
     mcf_engine::CandKey win{0, kNone};
     if (e->cand_ptr < e->cand_list.size()) {
         win = e->cand_list[e->cand_ptr];
@@ -1129,6 +1127,8 @@ int cand_collect(mcf_engine *e, uint32_t at)
         e->cand_list.resize(keep);
     }
     std::sort(e->cand_list.begin(), e->cand_list.end(), cand_key_less);
+    e->cand_ends.resize(2 * e->cand_list.size());
+    for (size_t i = 0; i < e->cand_list.size(); ++i) { e->cand_ends[2 * i] = e->h_src[e->cand_list[i].p]; e->cand_ends[2 * i + 1] = e->h_tgt[e->cand_list[i].p]; }
     e->cand_ptr = 0;
     e->cand_valid = true;
     e->snap_at = at;
@@ -1574,7 +1574,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
                     e->resident_reg = false;
                 }
                 e->cand_on = !(desc->flags & MCF_ENGINE_NO_CANDIDATES) && !(getenv("MCF_HIP_CANDIDATES") && getenv("MCF_HIP_CANDIDATES")[0] == '0') &&
-                             whole && e->resident_reg && desc->rule == MCF_RULE_BEST_ELIGIBLE &&
+                             whole && e->resident_reg && desc->rule == MCF_RULE_BEST_ELIGIBLE && desc->node_count < (1 << 29) &&
                              2 * (int64_t)desc->search_arc_num <= (int64_t)kCandMaxAvgDegree * desc->node_count;
             }
         }
@@ -1713,16 +1713,21 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
         e->adj_start.assign(n + 1, 0);
         for (int a = 0; a < m_s; ++a) { e->adj_start[source[a] + 1]++; if (target[a] != source[a]) e->adj_start[target[a] + 1]++; }
         for (int u = 0; u < n; ++u) e->adj_start[u + 1] += e->adj_start[u];
-        e->adj.assign(e->adj_start[n], mcf_engine::AdjEnt{0, 0, 0});
+        e->adj.assign(e->adj_start[n], mcf_engine::AdjEnt{0, 0u, 0});
+        e->adj_pos.assign((size_t)2 * m_s, -1);
         std::vector<int32_t> fill(e->adj_start.begin(), e->adj_start.end() - 1);
         for (int a = 0; a < m_s; ++a) {
-            e->adj[fill[source[a]]++] = mcf_engine::AdjEnt{a, target[a], cost[a]};
-            if (target[a] != source[a]) e->adj[fill[target[a]]++] = mcf_engine::AdjEnt{a, (int32_t)((uint32_t)source[a] | 0x80000000u), cost[a]};
+            const uint32_t st_bits = (uint32_t)(state[a] + 1) << 29;
+            e->adj_pos[2 * (size_t)a] = fill[source[a]];
+            e->adj[fill[source[a]]++] = mcf_engine::AdjEnt{a, (uint32_t)target[a] | st_bits, cost[a]};
+            if (target[a] != source[a]) {
+                e->adj_pos[2 * (size_t)a + 1] = fill[target[a]];
+                e->adj[fill[target[a]]++] = mcf_engine::AdjEnt{a, (uint32_t)source[a] | st_bits | 0x80000000u, cost[a]};
+            }
         }
         e->node_at.assign(n, 0u);
         e->arc_at.assign(m_s, 0u);
         e->arc_stamp.assign(m_s, 0u);
-        e->arc_seen.assign(m_s, 0u);
         e->cand_now = 1;
         e->snap_at = 0;
         e->heap_gap = 0;
@@ -1746,7 +1751,16 @@ int mcf_engine_patch_state(mcf_engine *e, int32_t count, const int32_t *arcs, co
         if (arcs[i] < 0 || arcs[i] >= e->d.arc_capacity) return mcf::fail(MCF_ERR_INVALID, "arc %d out of range", arcs[i]);
         if (states[i] < -1 || states[i] > 1) return mcf::fail(MCF_ERR_INVALID, "state %d is not -1/0/1", states[i]);
         if (arcs[i] < e->begin || arcs[i] >= e->end) continue;   // not resident here (outside the search range or another shard)
-        if (e->cand_on) { e->h_state[arcs[i]] = states[i]; cand_note_arc(e, arcs[i]); continue; }
+        if (e->cand_on) {
+            const int a = arcs[i];
+            e->h_state[a] = states[i];
+            for (int side = 0; side < 2; ++side) {             // the copies of the state beside the arc's two adjacency entries
+                const int q = e->adj_pos[2 * (size_t)a + side];
+                if (q >= 0) e->adj[q].other = (e->adj[q].other & ~(3u << 29)) | ((uint32_t)(states[i] + 1) << 29);
+            }
+            cand_note_arc(e, a);
+            continue;
+        }
         // the device addresses state[] by position: begin + position of the arc in the stored order
         if (e->bucket_nodes > 0 && e->pos_of.empty()) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
         const int32_t where = e->bucket_nodes > 0 ? e->begin + e->pos_of[arcs[i] - e->begin] : arcs[i];

@@ -8,6 +8,8 @@
 // entering-arc search in this file or anywhere else in the library.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -801,7 +803,7 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     const int64_t max_iter = std::max<int64_t>(1000000, (int64_t)s->n * (int64_t)s->m);   // NS.cs:280
     int64_t it = 0;
     bool limited = false;
-    double t_search = 0, t_tree = 0, t_pot = 0;
+    double t_search = 0, t_tree = 0, t_pot = 0, t_hand = 0, t_begin = 0;      // t_hand, t_begin: the last hand-over and the posting of the search, parts of t_pot
     s->hand_over = true;
     s->engine_rc = 0;
     // The search for pivot k+1 is posted as soon as the device has what it depends on (State[] writes, potentials); the rest of pivot k
@@ -823,8 +825,12 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         rc = s->engine_rc;
         if (!rc && s->moved_n > s->moved_sent)
             rc = engines_append_potential(s, (int32_t)(s->moved_n - s->moved_sent), s->moved.data() + s->moved_sent, s->moved_val.data() + s->moved_sent);
+        const double t2 = ticks();
         if (!rc) rc = engines_search_begin(s);
-        t_pot += ticks() - t1;
+        const double t3 = ticks();
+        t_pot += t3 - t1;
+        t_hand += t2 - t1;
+        t_begin += t3 - t2;
         if (rc) break;                     // the pivot stays half done: the solver is unusable after an engine error, but nothing is left running
         pivot_back(s, &t_tree);
         s->metrics.potential_nodes += (int64_t)s->moved_n;
@@ -842,6 +848,10 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     s->metrics.pivot_search_us = t_search * ns_per_tick / 1e3;
     s->metrics.tree_update_us = t_tree * ns_per_tick / 1e3;
     s->metrics.potential_update_us = t_pot * ns_per_tick / 1e3;
+    if (getenv("MCF_NS_DEBUG") && it > 1000)
+        fprintf(stderr, "[ns] per pivot ns: search wait %.0f | walk+pieces %.0f | last hand-over %.0f | search begin %.0f | tree %.0f | everything else %.0f\n",
+                t_search * ns_per_tick / it, (t_pot - t_hand - t_begin) * ns_per_tick / it, t_hand * ns_per_tick / it, t_begin * ns_per_tick / it, t_tree * ns_per_tick / it,
+                ((ticks() - tick_start) - t_search - t_pot - t_tree) * ns_per_tick / it);
     mcf_engine_get_stats(s->engine, &s->metrics.engine);
     // the rest of SolverMetrics: NS.cs:262-270 (initial block size), :276 (expected iterations), :344-357
     const bool plain_block = s->rule == MCF_RULE_BLOCK_SEARCH && !s->optimized_pivot;
