@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--no-validator", action="store_true", help="skip the SolutionValidator measurement")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact config-2 / config-4 blocks")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline sample")
-    ap.add_argument("--sharded-pivots", type=int, default=-1, help="N>1: pivots of config 5 timed with the arcs sharded over the ranks (-1 = 2000 when N > 1, 0 = skip)")
+    ap.add_argument("--sharded-pivots", type=int, default=-1, help="N>1: pivots of config 5 timed with the arcs sharded over the ranks (-1 = 5000 when N > 1, 0 = skip)")
     ap.add_argument("--dispatch", action="store_true", help="one scan dispatch per search instead of the resident grid")
     ap.add_argument("--concurrent", type=int, default=4, help="extra measurement: this many independent solves at once on the GPU (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo: rehearsals on one GPU)")
@@ -178,7 +178,8 @@ def sharded_leg(M, torch, dist, args, rank, world, dev, barrier, red_dev):
 
         def rccl_leg():
             ident = torch.from_numpy(M.comm_unique_id() if rank == 0 else np.zeros(128, "uint8")).cuda()
-            dist.broadcast(ident, src=0)
+            if dist is not None:
+                dist.broadcast(ident, src=0)
             box["res"] = run(lambda ns: ns.set_sharding(ident.cpu().numpy(), rank, world))
 
         th = threading.Thread(target=rccl_leg, daemon=True)
@@ -417,7 +418,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to label a {world}-rank run as {args.gpus} GPUs")
     if args.sharded_pivots < 0:
-        args.sharded_pivots = 2000 if world > 1 else 0
+        args.sharded_pivots = 5000 if world > 1 else 0
 
     import torch
     import mincostflow_amd as M
@@ -481,7 +482,7 @@ def main():
         pivots_all = pivots
 
     sharded = None
-    if dist is not None and args.sharded_pivots > 0:
+    if args.sharded_pivots > 0:            # by default only for N > 1; `--sharded-pivots P` with one rank runs the same legs with a world of 1
         sharded = sharded_leg(M, torch, dist, args, rank, world, dev, barrier, red_dev)
 
     abandon = bool(sharded and sharded.pop("abandon_process_group", False))

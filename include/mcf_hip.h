@@ -179,6 +179,12 @@ MCF_API int mcf_engine_append_potential(mcf_engine *e, int32_t count, const int3
  * then shift those by sigma directly, for short lists inside the next search's dispatch. */
 MCF_API int mcf_engine_shift_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values, int64_t sigma);
 
+/* Optional: the caller keeps _pi anyway (the host solver does: sigma needs _pi[_vIn] and _pi[_uIn], NS.cs:1187-1190) -- bind that array
+ * (int64[node_count], must outlive the binding; NULL unbinds) and the engine reads potentials from it instead of keeping a copy of its
+ * own up to date.  Contract: when a search begins the array holds the values announced by set / append / shift_potential since the last
+ * search, and it does not change while a search is in flight.  mcf_engine_update_potential (+= sigma) is not available while bound. */
+MCF_API int mcf_engine_bind_potentials(mcf_engine *e, const int64_t *pi);
+
 /* Rewrites (source, target, cost) of arcs, e.g. artificial arcs re-pointed by a warm start. Synchronous. */
 MCF_API int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, const int32_t *source,
                                   const int32_t *target, const int64_t *cost);

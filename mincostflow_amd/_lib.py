@@ -122,6 +122,7 @@ SIGNATURES = {
     "mcf_engine_update_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, C.c_int64]),
     "mcf_engine_set_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i64p]),
     "mcf_engine_append_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i64p]),
+    "mcf_engine_bind_potentials": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mcf_engine_shift_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i64p, C.c_int64]),
     "mcf_engine_patch_arcs": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, _i64p]),
     "mcf_engine_find_entering": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),

@@ -123,6 +123,7 @@ struct mcf_engine {
     // host mirror of pi: patches carry final values
     std::vector<int64_t> pi;
     bool mirror_valid = false;     // mcf_engine_set_potential stops maintaining the mirror; update_potential rebuilds it on demand
+    const int64_t *ext_pi = nullptr;   // mcf_engine_bind_potentials: the caller's own array is read instead of the mirror (no second copy to keep up to date)
     int64_t max_abs_cost = 0;
     // pending patches of the current pivot
     std::vector<int32_t> pend_node, pend_arc, pend_state;
@@ -913,6 +914,7 @@ int collect(mcf_engine *e, int grid, Key *out)
 constexpr int64_t kCandMaxPivotDegree = 1024;   // adjacency entries re-evaluated per pivot at most
 constexpr int kCandMaxAvgDegree = 24;           // denser graphs: a single moved node already touches too many arcs
 
+inline const int64_t *cand_pi(const mcf_engine *e) { return e->ext_pi ? e->ext_pi : e->pi.data(); }
 inline bool cand_key_less(const mcf_engine::CandKey &a, const mcf_engine::CandKey &b) { return a.c < b.c || (a.c == b.c && a.p < b.p); }
 struct CandHeapAfter {        // std::*_heap keep the LARGEST on top: order by "comes later"
     bool operator()(const mcf_engine::HeapEnt &a, const mcf_engine::HeapEnt &b) const { return b.c < a.c || (b.c == a.c && b.p < a.p); }
@@ -960,7 +962,8 @@ inline void cand_push(mcf_engine *e, int a)
     const uint32_t stamp = ++e->arc_stamp[a];
     const int st = e->h_state[a];
     if (st == 0) return;
-    const int64_t d = e->h_cost[a] + e->pi[e->h_src[a]] - e->pi[e->h_tgt[a]];
+    const int64_t *pi = cand_pi(e);
+    const int64_t d = e->h_cost[a] + pi[e->h_src[a]] - pi[e->h_tgt[a]];
     const int64_t rc = st > 0 ? d : -d;
     if (rc >= 0) return;
     e->heap.push_back(mcf_engine::HeapEnt{rc, (uint32_t)a, stamp});
@@ -975,7 +978,7 @@ void cand_absorb_pivot(mcf_engine *e)
         // arcs next to the moved nodes keep heap entries of older versions: they must not be taken for current ones
         // (entries are only trusted for snapshots taken at or after heap_gap, and those know the arcs' present keys -- see cand_decide)
     } else {
-        const int64_t *pi = e->pi.data();
+        const int64_t *pi = cand_pi(e);
         for (int u : e->pivot_nodes) {
             const int64_t pu = pi[u];
             // everything an evaluation needs sits in the entry except the other end's potential and the arc's version counter; an arc
@@ -1055,6 +1058,7 @@ int cand_build_patches(mcf_engine *e)
     // Every entry of a node must carry the same value (the device applies a list in no particular order).  Entries gathered here do (they
     // are read from the mirror now); the big lists do when they are ONE pivot's list of this very epoch (its pieces repeat no node
     // and nothing can have changed since) -- otherwise their values are read again too, and nothing of them may have travelled yet.
+    const int64_t *pi = cand_pi(e);
     const size_t n_b = e->blind_count, n_s = e->sync_nodes.size();
     const bool blind_current = n_b == 0 || (e->blind_epoch == e->cand_now && e->blind_sets <= 1);
     const bool squeeze = (int64_t)n_b + (int64_t)n_s > e->patch_capacity;            // lists may repeat nodes: squeeze the repeats out
@@ -1064,12 +1068,12 @@ int cand_build_patches(mcf_engine *e)
         std::sort(e->pend_node.begin(), e->pend_node.end());
         e->pend_node.erase(std::unique(e->pend_node.begin(), e->pend_node.end()), e->pend_node.end());
         e->pend_val.resize(e->pend_node.size());
-        for (size_t i = 0; i < e->pend_node.size(); ++i) e->pend_val[i] = e->pi[e->pend_node[i]];
+        for (size_t i = 0; i < e->pend_node.size(); ++i) e->pend_val[i] = pi[e->pend_node[i]];
     } else {
-        if (!blind_current) for (size_t i = 0; i < n_b; ++i) e->pend_val[i] = e->pi[e->pend_node[i]];
+        if (!blind_current) for (size_t i = 0; i < n_b; ++i) e->pend_val[i] = pi[e->pend_node[i]];
         e->pend_node.resize(n_b + n_s);
         e->pend_val.resize(n_b + n_s);
-        for (size_t i = 0; i < n_s; ++i) { e->pend_node[n_b + i] = e->sync_nodes[i]; e->pend_val[n_b + i] = e->pi[e->sync_nodes[i]]; }
+        for (size_t i = 0; i < n_s; ++i) { e->pend_node[n_b + i] = e->sync_nodes[i]; e->pend_val[n_b + i] = pi[e->sync_nodes[i]]; }
     }
     e->pend_arc.assign(e->sync_arcs.begin(), e->sync_arcs.end());
     e->pend_state.resize(e->pend_arc.size());
@@ -1783,6 +1787,7 @@ int mcf_engine_update_potential(mcf_engine *e, int32_t count, const int32_t *nod
     if (!e || count < 0 || (count && !nodes)) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_update_potential: bad arguments");
     if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
     if (count == 0) return MCF_OK;
+    if (e->ext_pi) return mcf::fail(MCF_ERR_STATE, "the potentials are bound to the caller's array (mcf_engine_bind_potentials): pass the new values with set / append / shift_potential");
     if (!e->mirror_valid) {          // the caller switched from set_potential to += sigma: fetch the current values once
         int rc = mcf_engine_download_pi(e, e->pi.data());
         if (rc) return rc;
@@ -1836,7 +1841,7 @@ int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes,
         if (narrow && !fits32(values[i])) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d leaves int32; create the engine with int_width 64", nodes[i]);
     }
     if (e->cand_on) {                 // the mirror stays authoritative in candidate mode
-        for (int i = 0; i < count; ++i) e->pi[nodes[i]] = values[i];
+        if (!e->ext_pi) for (int i = 0; i < count; ++i) e->pi[nodes[i]] = values[i];      // bound potentials: the caller's array already holds them
         if (count > e->cand_max_nodes || e->pivot_overflow) { const int rcn = cand_note_nodes_blind(e, count, nodes, values, e->cand_appending); if (rcn) return rcn; }
         else for (int i = 0; i < count; ++i) cand_note_node(e, nodes[i]);
         e->st.potential_nodes += count;
@@ -1876,6 +1881,15 @@ int mcf_engine_append_potential(mcf_engine *e, int32_t count, const int32_t *nod
     e->mirror_valid = false;
     e->st.potential_nodes += count;
     resident_stream(e);
+    return MCF_OK;
+}
+
+int mcf_engine_bind_potentials(mcf_engine *e, const int64_t *pi)
+{
+    if (!e) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_bind_potentials: null engine");
+    if (e->in_flight != mcf_engine::kNoSearch) return mcf::fail(MCF_ERR_STATE, "mcf_engine_bind_potentials: a search is in flight");
+    e->ext_pi = pi;
+    if (!pi) e->mirror_valid = false;
     return MCF_OK;
 }
 

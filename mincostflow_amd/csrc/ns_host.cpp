@@ -64,6 +64,7 @@ struct mcf_ns {
     int moved_n = 0;
     int moved_sent = 0;               // how many of them the engine already has (handed over during the walk)
     int engine_rc = 0;                // first error of an engine call made from inside a pivot
+    double piece_ticks = 0;           // time inside the hand-over calls made during the walks (part of the potential-update bucket)
     bool hand_over = false;           // a device engine is attached: state writes and potential pieces go to it as they arise
     int64_t sigma = 0;
     // engine(s) + sharding.  kRccl / kHost: one process per GPU, this rank's engine holds one arc shard and the candidates are exchanged
@@ -414,7 +415,9 @@ void shift_potentials(mcf_ns *s)
         a = nxt[a];
         if (s->hand_over && i + 1 - s->moved_sent >= piece && count - (i + 1) >= piece / 2) {
             // the grid applies this piece while the walk goes on (resident mode); the search after the pivot finishes the list
+            const double tp = ticks();
             if (!s->engine_rc) s->engine_rc = engines_append_potential(s, i + 1 - s->moved_sent, nodes + s->moved_sent, vals + s->moved_sent);
+            s->piece_ticks += ticks() - tp;
             s->moved_sent = i + 1;
         }
     }
@@ -771,6 +774,8 @@ int mcf_ns_prepare(mcf_ns *s)
         if (s->shard_mode == mcf_ns::kRccl) { rc = mcf_engine_comm_init(e, s->nccl_id, s->rank, s->world); if (rc) return rc; }
         rc = mcf_engine_set_block_config(e, &s->config, s->n);
         if (rc) return rc;
+        rc = mcf_engine_bind_potentials(e, s->pi.data());       // this solver's _pi is current whenever a search begins and still while it is in flight
+        if (rc) return rc;
     }
     s->cands.assign((size_t)std::max(1, s->world), mcf_candidate{0, 0xFFFFFFFFu, -1});
     if (s->shard_mode == mcf_ns::kHost) { rc = mcf_exchange_open(&s->exchange, s->exchange_name.c_str(), s->rank, s->world); if (rc) return rc; }
@@ -806,6 +811,7 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     double t_search = 0, t_tree = 0, t_pot = 0, t_hand = 0, t_begin = 0;      // t_hand, t_begin: the last hand-over and the posting of the search, parts of t_pot
     s->hand_over = true;
     s->engine_rc = 0;
+    s->piece_ticks = 0;
     // The search for pivot k+1 is posted as soon as the device has what it depends on (State[] writes, potentials); the rest of pivot k
     // (flows around the cycle, re-hanging the subtree) runs while the device is searching.  Engines sharded over RCCL search in one
     // blocking call (the all-gather runs on their stream), so for them the two halves simply follow each other.
@@ -849,8 +855,8 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     s->metrics.tree_update_us = t_tree * ns_per_tick / 1e3;
     s->metrics.potential_update_us = t_pot * ns_per_tick / 1e3;
     if (getenv("MCF_NS_DEBUG") && it > 1000)
-        fprintf(stderr, "[ns] per pivot ns: search wait %.0f | walk+pieces %.0f | last hand-over %.0f | search begin %.0f | tree %.0f | everything else %.0f\n",
-                t_search * ns_per_tick / it, (t_pot - t_hand - t_begin) * ns_per_tick / it, t_hand * ns_per_tick / it, t_begin * ns_per_tick / it, t_tree * ns_per_tick / it,
+        fprintf(stderr, "[ns] per pivot ns: search wait %.0f | walk %.0f | pieces handed over during walks %.0f | last hand-over %.0f | search begin %.0f | tree %.0f | everything else %.0f\n",
+                t_search * ns_per_tick / it, (t_pot - t_hand - t_begin - s->piece_ticks) * ns_per_tick / it, s->piece_ticks * ns_per_tick / it, t_hand * ns_per_tick / it, t_begin * ns_per_tick / it, t_tree * ns_per_tick / it,
                 ((ticks() - tick_start) - t_search - t_pot - t_tree) * ns_per_tick / it);
     mcf_engine_get_stats(s->engine, &s->metrics.engine);
     // the rest of SolverMetrics: NS.cs:262-270 (initial block size), :276 (expected iterations), :344-357
