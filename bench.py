@@ -390,6 +390,10 @@ def pin_near_gpu(dev):
             cpus.update(range(int(lo), int(hi or lo) + 1))
         cpus &= os.sched_getaffinity(0)
         if cpus:
+            # MCF_BENCH_PIN=core: one core of that node (the one this thread is on, if it belongs to it) instead of the whole node
+            if os.environ.get("MCF_BENCH_PIN") == "core":
+                here = os.sched_getcpu()
+                cpus = {here} if here in cpus else {min(cpus)}
             os.sched_setaffinity(0, cpus)
             return node
     except Exception:
