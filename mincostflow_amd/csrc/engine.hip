@@ -110,6 +110,7 @@ struct mcf_engine {
     bool rc_mode = false;
     bool rc_lds = false;           // resident RC grid: every workgroup's window of arcs fits LDS
     int rc_window = 0;             // arcs per workgroup in that case
+    int rc_threads = kThreads;     // workgroup width of the dispatched RC scan
     int64_t *d_rc = nullptr;
     int32_t *d_adj_start = nullptr;
     uint32_t *d_adj = nullptr;     // the shard's arcs at each node: local position, bit 31 = the node is the arc's target
@@ -373,7 +374,7 @@ bool rc_inline_ok(const mcf_engine *e)
 template <int RULE, bool OPT>
 void launch_rc_u(mcf_engine *e, const RcParams &p, hipEvent_t start, hipEvent_t stop)
 {
-    const dim3 grid(e->grid), block(kThreads);
+    const dim3 grid(e->grid), block(e->rc_threads);
     if (e->unroll == 4) {
         if (start) hipExtLaunchKernelGGL((scan_rc_kernel<RULE, OPT, 4>), grid, block, 0, e->stream, start, stop, 0, p);
         else hipLaunchKernelGGL((scan_rc_kernel<RULE, OPT, 4>), grid, block, 0, e->stream, p);
@@ -1486,12 +1487,14 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         e->rc_mode = want;
         if (e->rc_mode) {
             // pure streaming: more bytes in flight per thread, the grid sized so that every workgroup gets the same number of trips
-            // measured on config 5's arrays (profiles/r02_rc_layout_scan.txt): 1024 workgroups, one tile per trip -- 14.7 us warm / 16.4 cold
-            // for 81 MB; more workgroups or deeper trips only add launch ramp and tail
-            e->unroll = 1;
+            // measured on config 5's arrays (profiles/r02_rc_layout_scan.txt, r02_rc_layout_scan_threads.txt): everything between 256 and 1024
+            // workgroups of 256 .. 1024 threads lands within 14.3-15.6 us warm / 16.6-17.7 cold for 81 MB; 512 x 256 with two tiles per trip is
+            // the best of them, more workgroups only add launch ramp and tail
+            e->unroll = count > (1 << 20) ? 2 : 1;
             if (const char *u = getenv("MCF_HIP_UNROLL")) { const int v = atoi(u); if (v == 1 || v == 2 || v == 4) e->unroll = v; }
-            const int groups_rc = std::max(1, e->count_padded / (kTile * e->unroll));
-            const int max_rc = getenv("MCF_HIP_MAXWG") ? max_wg : 1024;
+            if (const char *u = getenv("MCF_HIP_RC_THREADS")) { const int v = atoi(u); if (v == 256 || v == 512 || v == 1024) e->rc_threads = v; }
+            const int groups_rc = std::max(1, e->count_padded / (e->rc_threads * kArcsPerThread * e->unroll));
+            const int max_rc = getenv("MCF_HIP_MAXWG") ? max_wg : 512;
             e->grid = desc->scan_workgroups > 0 ? std::min(desc->scan_workgroups, kMaxWorkgroups) : std::min(groups_rc, max_rc);
             e->grid = std::max(1, std::min(e->grid, groups_rc));
         }

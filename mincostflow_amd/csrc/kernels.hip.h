@@ -384,9 +384,9 @@ struct RcParams {
 };
 
 template <int RULE, bool OPT, int UNROLL>
-__global__ __launch_bounds__(kThreads) void scan_rc_kernel(const RcParams p)
+__global__ __launch_bounds__(kResidentThreads) void scan_rc_kernel(const RcParams p)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nt = (int)blockDim.x, tile = nt * kArcsPerThread;      // 256 .. 1024 threads per workgroup (the host's choice)
     if (p.n_st | p.n_pi) {
         // the State[] writes of the previous pivot: final values, applied by EVERY workgroup before it reads
         if (tid < p.n_st) {
@@ -397,13 +397,13 @@ __global__ __launch_bounds__(kThreads) void scan_rc_kernel(const RcParams p)
         // (tile t belongs to workgroup t mod grid), so every arc is shifted exactly once, by its only reader, before that reader reads
         // it -- no ordering between workgroups is needed.  An arc between two moved nodes appears twice (+sigma, -sigma): atomics.
         const int total = p.n_pi ? p.prefix[p.n_pi] : 0;
-        for (int f = tid; f < total; f += kThreads) {
+        for (int f = tid; f < total; f += nt) {
             int k = 0;
             for (int step = kRcInlineNodes / 2; step > 0; step >>= 1)        // largest k with prefix[k] <= f
                 if (k + step < p.n_pi && p.prefix[k + step] <= f) k += step;
             const uint32_t x = p.adj[p.adj_lo[k] + (f - p.prefix[k])];
             const uint32_t pos = x & 0x7FFFFFFFu;
-            if ((int)((pos / (uint32_t)(kTile * UNROLL)) % gridDim.x) == (int)blockIdx.x) {
+            if ((int)((pos / (uint32_t)(tile * UNROLL)) % gridDim.x) == (int)blockIdx.x) {
                 const long long add = (x >> 31) ? -p.sigma : p.sigma;
                 atomicAdd(reinterpret_cast<unsigned long long *>(p.rc + pos), (unsigned long long)add);
             }
@@ -420,13 +420,13 @@ __global__ __launch_bounds__(kThreads) void scan_rc_kernel(const RcParams p)
     best.r = kNone;
     best.p = kNone;
     typedef long v2l __attribute__((ext_vector_type(2)));
-    const int step = gridDim.x * kTile * UNROLL;
-    for (int i0 = blockIdx.x * kTile * UNROLL + tid * kArcsPerThread; i0 < p.count_padded; i0 += step) {
+    const int step = gridDim.x * tile * UNROLL;
+    for (int i0 = blockIdx.x * tile * UNROLL + tid * kArcsPerThread; i0 < p.count_padded; i0 += step) {
         uint32_t st4[UNROLL];
         v2l a[UNROLL], b[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {       // streamed once per scan: non-temporal, all loads of the trip in flight together
-            const int i = i0 + u * kTile;
+            const int i = i0 + u * tile;
             st4[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p.state_ro + i));
             a[u] = __builtin_nontemporal_load(reinterpret_cast<const v2l *>(p.rc + i));
             b[u] = __builtin_nontemporal_load(reinterpret_cast<const v2l *>(p.rc + i + 2));
@@ -434,10 +434,10 @@ __global__ __launch_bounds__(kThreads) void scan_rc_kernel(const RcParams p)
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int64_t d[4] = {a[u].x, a[u].y, b[u].x, b[u].y};
-            fold_rc<RULE, OPT>(st4[u], d, p.base + i0 + u * kTile, p.m_s, p.next_arc, p.block_size, p.rstar, best);
+            fold_rc<RULE, OPT>(st4[u], d, p.base + i0 + u * tile, p.m_s, p.next_arc, p.block_size, p.rstar, best);
         }
     }
-    publish_best<RULE, false>(best, p.slots + (size_t)blockIdx.x * kSlotStride, p.seq, true);
+    publish_best<RULE, false, kResidentThreads>(best, p.slots + (size_t)blockIdx.x * kSlotStride, p.seq, true);
 }
 
 // d[e] = cost[e] + pi[source[e]] - pi[target[e]] for every stored arc (upload, mcf_engine_patch_arcs); padding arcs have state 0

@@ -31,6 +31,13 @@ def scan(label, env):
     return f
 
 ref = scan("gathering scan, bucketed (round 1)", {"MCF_HIP_RC": 0})
+if len(sys.argv) > 1 and sys.argv[1] == "threads":
+    for threads in (256, 512, 1024):
+        for wg in (256, 512, 1024, 2048):
+            for unroll in (1, 2):
+                got = scan(f"RC layout {threads} threads unroll {unroll} max workgroups {wg}", {"MCF_HIP_RC": 1, "MCF_HIP_RC_THREADS": threads, "MCF_HIP_UNROLL": unroll, "MCF_HIP_MAXWG": wg})
+                assert got == ref, (got, ref)
+    sys.exit(0)
 for unroll in (1, 2, 4):
     for wg in (1024, 2048, 4096, 8192):
         got = scan(f"RC layout unroll {unroll} max workgroups {wg}", {"MCF_HIP_RC": 1, "MCF_HIP_UNROLL": unroll, "MCF_HIP_MAXWG": wg})
