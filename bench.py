@@ -82,12 +82,16 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(g, rule, budget_s):
+def cpu_baseline(g, rule, budget_s, reference_default=False):
     """Oracle (C port of the reference, EnableOptimizedPivot semantics), same instance and rule, one core; with the reference's three
-    phase buckets (SolverMetrics: pivot search / tree update / potential update)."""
+    phase buckets (SolverMetrics: pivot search / tree update / potential update).
+    reference_default: the plain rule with the reference's auto-configuration instead -- what `new NetworkSimplex(g).Solve()` runs."""
     from oracle import ns_oracle as O
     p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
-    o = O.Oracle(p, O.SEM_CSHARP_OPT, {0: O.RULE_FIRST, 1: O.RULE_BEST, 2: O.RULE_BLOCK}[rule])
+    if reference_default:
+        o = O.Oracle(p, O.SEM_CSHARP, {0: O.RULE_FIRST, 1: O.RULE_BEST, 2: O.RULE_BLOCK}[rule], auto_config=True)
+    else:
+        o = O.Oracle(p, O.SEM_CSHARP_OPT, {0: O.RULE_FIRST, 1: O.RULE_BEST, 2: O.RULE_BLOCK}[rule])
     o.enable_timing()
     o.init()
     done, ended, t0 = 0, False, time.perf_counter()
@@ -617,6 +621,15 @@ def main():
         if rule != M.PivotRule.BlockSearch:
             blk = cpu_baseline(g, M.PivotRule.BlockSearch, args.cpu_seconds)
             line["cpu_baseline_block_search"] = blk       # the reference's default rule, for the cross-rule comparison
+            dflt = cpu_baseline(g, M.PivotRule.BlockSearch, max(args.cpu_seconds, 45.0), reference_default=True)      # long enough to finish: 1.1 M pivots
+            dflt["what"] = "new NetworkSimplex(g).Solve(): plain Block Search with the reference's auto-configuration (SmallBlocksForDense / adaptive block size as its analyser picks them)"
+            line["cpu_baseline_reference_default"] = dflt
+            line["solve_time_vs_cpu"] = {"gpu_best_eligible_ms": line["solve_ms"],
+                                         "cpu_port_best_eligible_ms_extrapolated": line["pivots_per_solve"] / line["cpu_baseline"]["value"] * 1e3,
+                                         "cpu_port_block_search_optimized_ms": blk["solve_ms_if_whole"], "cpu_port_reference_default_ms": dflt["solve_ms_if_whole"],
+                                         "note": "like for like (Best Eligible) the GPU path is tens of times faster; against the CPU port of EnableOptimizedPivot's Block Search (fixed block of "
+                                                 "sqrt(m) arcs) it is about twice as fast, not ten times; against what `new NetworkSimplex(g).Solve()` actually runs -- the plain Block "
+                                                 "Search whose adaptive rule shrinks the block to its minimum on this instance and needs 1.1 M pivots -- it is more than ten times faster"}
     if not args.no_other_configs and args.gpus == 1 and args.workload == "config3":
         line["other_configs"] = {c: other_config(M, c, local_rank, 0 if args.no_cpu_baseline else min(args.cpu_seconds, 8.0)) for c in ("config2", "config4")}
     if not args.no_microbench and args.gpus == 1:
