@@ -1164,6 +1164,28 @@ int cand_post(mcf_engine *e)
     return MCF_OK;
 }
 
+// the host mirrors' arc lists per node, with what a re-evaluation needs next to each other (upload, mcf_engine_patch_arcs)
+void cand_build_adjacency(mcf_engine *e)
+{
+    const int n = e->d.node_count, m_s = e->d.search_arc_num;
+    const int32_t *source = e->h_src.data(), *target = e->h_tgt.data();
+    e->adj_start.assign(n + 1, 0);
+    for (int a = 0; a < m_s; ++a) { e->adj_start[source[a] + 1]++; if (target[a] != source[a]) e->adj_start[target[a] + 1]++; }
+    for (int u = 0; u < n; ++u) e->adj_start[u + 1] += e->adj_start[u];
+    e->adj.assign(e->adj_start[n], mcf_engine::AdjEnt{0, 0u, 0});
+    e->adj_pos.assign((size_t)2 * m_s, -1);
+    std::vector<int32_t> fill(e->adj_start.begin(), e->adj_start.end() - 1);
+    for (int a = 0; a < m_s; ++a) {
+        const uint32_t st_bits = (uint32_t)(e->h_state[a] + 1) << 29;
+        e->adj_pos[2 * (size_t)a] = fill[source[a]];
+        e->adj[fill[source[a]]++] = mcf_engine::AdjEnt{a, (uint32_t)target[a] | st_bits, e->h_cost[a]};
+        if (target[a] != source[a]) {
+            e->adj_pos[2 * (size_t)a + 1] = fill[target[a]];
+            e->adj[fill[target[a]]++] = mcf_engine::AdjEnt{a, (uint32_t)source[a] | st_bits | 0x80000000u, e->h_cost[a]};
+        }
+    }
+}
+
 // forgets the list and the heap (upload, or the device state was changed behind the cache's back)
 void cand_reset(mcf_engine *e)
 {
@@ -1717,21 +1739,7 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
         e->h_tgt.assign(target, target + m_s);
         e->h_cost.assign(cost, cost + m_s);
         e->h_state.assign(state, state + m_s);
-        e->adj_start.assign(n + 1, 0);
-        for (int a = 0; a < m_s; ++a) { e->adj_start[source[a] + 1]++; if (target[a] != source[a]) e->adj_start[target[a] + 1]++; }
-        for (int u = 0; u < n; ++u) e->adj_start[u + 1] += e->adj_start[u];
-        e->adj.assign(e->adj_start[n], mcf_engine::AdjEnt{0, 0u, 0});
-        e->adj_pos.assign((size_t)2 * m_s, -1);
-        std::vector<int32_t> fill(e->adj_start.begin(), e->adj_start.end() - 1);
-        for (int a = 0; a < m_s; ++a) {
-            const uint32_t st_bits = (uint32_t)(state[a] + 1) << 29;
-            e->adj_pos[2 * (size_t)a] = fill[source[a]];
-            e->adj[fill[source[a]]++] = mcf_engine::AdjEnt{a, (uint32_t)target[a] | st_bits, cost[a]};
-            if (target[a] != source[a]) {
-                e->adj_pos[2 * (size_t)a + 1] = fill[target[a]];
-                e->adj[fill[target[a]]++] = mcf_engine::AdjEnt{a, (uint32_t)source[a] | st_bits | 0x80000000u, cost[a]};
-            }
-        }
+        cand_build_adjacency(e);
         e->node_at.assign(n, 0u);
         e->arc_at.assign(m_s, 0u);
         e->arc_stamp.assign(m_s, 0u);
@@ -1915,6 +1923,7 @@ int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, con
     if (!rc) rc = flush_pending(e);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
+    bool cand_touched = false;
     for (int i = 0; i < count; ++i) {
         const int a = arcs[i];
         if (a < 0 || a >= e->d.arc_capacity) return mcf::fail(MCF_ERR_INVALID, "arc %d out of range", a);
@@ -1922,7 +1931,7 @@ int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, con
         if (a < e->begin || a >= e->end) continue;
         if (e->bucket_nodes > 0 && e->pos_of.empty()) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
         const int l = e->bucket_nodes > 0 ? e->pos_of[a - e->begin] : a - e->begin;     // the arc keeps its position even if its target leaves the range
-        if (e->cand_on) return mcf::fail(MCF_ERR_STATE, "mcf_engine_patch_arcs is not available with MCF_ENGINE_CANDIDATES (upload again)");
+        if (e->cand_on) { e->h_src[a] = source[i]; e->h_tgt[a] = target[i]; e->h_cost[a] = cost[i]; cand_touched = true; }
         HIP_TRY(hipMemcpy(e->d_src + l, &source[i], 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(e->d_tgt + l, &target[i], 4, hipMemcpyHostToDevice));
         if (e->d.int_width == 32) {
@@ -1932,6 +1941,11 @@ int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, con
         } else {
             HIP_TRY(hipMemcpy((int64_t *)e->d_cost + l, &cost[i], 8, hipMemcpyHostToDevice));
         }
+    }
+    if (cand_touched) {      // the candidate cache's mirrors: new arc lists, and nothing it knew about keys holds any more
+        cand_build_adjacency(e);
+        cand_reset(e);
+        e->async_posted = false;
     }
     if (e->rc_mode) {        // end points and costs changed: the arcs' reduced costs and the nodes' arc lists are rebuilt from the device arrays
         const int cnt = e->end - e->begin;
