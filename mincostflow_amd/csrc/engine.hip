@@ -1207,6 +1207,20 @@ int search_begin(mcf_engine *e)
     const bool had = !e->pend_node.empty() || !e->pend_arc.empty();
     // a resident grid needs one of the device's slots; without one this search is served by a dispatch (the arrays are the same)
     const bool resident_now = e->resident_ok && (e->resident_running || resident_slot_acquire(e));
+    if (e->cand_on && e->cand_now >= 0xFFFFFF00u && !e->async_posted) {
+        // the epoch counter is about to wrap (four billion searches): start over with nothing known -- the device searches next
+        std::fill(e->node_at.begin(), e->node_at.end(), 0u);
+        std::fill(e->arc_at.begin(), e->arc_at.end(), 0u);
+        const bool overflow = e->pivot_overflow;
+        const std::vector<int32_t> pn = e->pivot_nodes, pa = e->pivot_arcs;
+        cand_reset(e);
+        e->cand_now = 1;
+        e->snap_at = 0;
+        e->heap_gap = 1;
+        e->pivot_overflow = overflow;                       // this pivot's changes are still to be shipped (sync lists are untouched)
+        for (int u : pn) e->node_at[u] = 1;
+        for (int a : pa) e->arc_at[a] = 1;
+    }
     if (e->cand_on) {
         const double ta = (double)__rdtsc();
         if (e->pivot_overflow) e->n_gap_pivots += 1;
@@ -1750,6 +1764,7 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
         e->sync_nodes.clear(); e->sync_arcs.clear(); e->blind_count = 0;
         cand_reset(e);
         e->heap_gap = 0;
+        if (const char *u = getenv("MCF_HIP_CAND_EPOCH0")) { const unsigned long long v = strtoull(u, nullptr, 10); if (v >= 1 && v <= 0xFFFFFFFFull) e->cand_now = (uint32_t)v; }    // tests: start close to the wrap
         if (const char *u = getenv("MCF_HIP_CAND_NODES")) { const int v = atoi(u); if (v >= 0 && v <= 4096) e->cand_max_nodes = v; }
         if (const char *u = getenv("MCF_HIP_CAND_REFRESH")) { const int v = atoi(u); if (v >= 0 && v <= 4096) e->cand_refresh_low = v; }
     }

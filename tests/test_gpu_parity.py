@@ -930,3 +930,16 @@ def test_rc_layout_shards_and_shard_group(monkeypatch):
     ns.set_shard_group([0, 0]).record_trace(1 << 22)
     assert ns.solve() == st_o == O.OPTIMAL and np.array_equal(ns.trace(), tr_o)
     assert ns.get_metrics()["engine"]["rc_layout"] == 1
+
+
+@pytest.mark.gpu
+def test_candidate_cache_survives_the_wrap_of_its_epoch_counter(monkeypatch):
+    """Every search has an epoch number (32 bits); MCF_HIP_CAND_EPOCH0 starts the counter 300 searches before it would wrap: the cache starts
+    over there and the pivots stay the oracle's."""
+    monkeypatch.setenv("MCF_HIP_CAND_EPOCH0", str(0xFFFFFF00 - 300))
+    p = load("netgen_8_13a")
+    o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, O.RULE_BEST)
+    assert st == st_o == O.OPTIMAL and len(tr_o) > 5000
+    assert np.array_equal(ns.trace(), tr_o), int(np.argmax(ns.trace()[: len(tr_o)] != tr_o[: len(ns.trace())]))
+    e = ns.get_metrics()["engine"]
+    assert e["candidates"] == 1 and e["host_decided"] > e["resident_requests"]
