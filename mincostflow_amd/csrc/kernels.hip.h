@@ -448,30 +448,52 @@ __global__ __launch_bounds__(kThreads) void rc_init_kernel(const int32_t *src, c
     if (i < count_padded) rc[i] = (int64_t)cost[i] + (int64_t)pi[src[i]] - (int64_t)pi[tgt[i]];
 }
 
-// pi[node[i]] = value[i] and the change carried over to the node's arcs; state[arc[j]] = s[j].  One thread per node: the nodes of a
-// list are distinct (the caller's contract), so every node's change is computed and applied exactly once.
+// pi[node[i]] = value[i] and the change carried over to the node's arcs; state[arc[j]] = s[j].  One thread per node (a hub's arc list is
+// walked by its whole workgroup): the nodes of a list are distinct (the caller's contract), so every node's change is computed and applied exactly once.
 // adj: the shard's arcs incident to each node as local positions, bit 31 set when the node is the arc's TARGET.
+constexpr int kRcHeavyDegree = 512;         // a node with a longer arc list is shifted by its whole workgroup, not by one thread
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void update_rc_kernel(T *pi, const int32_t *nodes, const int64_t *values, int n_pi, int8_t *state, const int32_t *arcs,
                                                              const int32_t *states, int n_st, int base, int count_padded, int64_t *rc,
                                                              const int32_t *adj_start, const uint32_t *adj)
 {
-    const int i = blockIdx.x * kThreads + threadIdx.x;
+    __shared__ int32_t heavy_lo[kThreads], heavy_hi[kThreads];
+    __shared__ int64_t heavy_delta[kThreads];
+    __shared__ int heavy_n;
+    const int tid = threadIdx.x, i = blockIdx.x * kThreads + tid;
+    if (tid == 0) heavy_n = 0;
+    __syncthreads();
     if (i < n_pi) {
         const int u = nodes[i];
         const int64_t delta = values[i] - (int64_t)pi[u];
         pi[u] = (T)values[i];
         if (delta != 0) {
-            for (int k = adj_start[u], hi = adj_start[u + 1]; k < hi; ++k) {
-                const uint32_t x = adj[k];
-                const long long add = (x >> 31) ? -delta : delta;
-                atomicAdd(reinterpret_cast<unsigned long long *>(rc + (x & 0x7FFFFFFFu)), (unsigned long long)add);
+            const int lo = adj_start[u], hi = adj_start[u + 1];
+            if (hi - lo > kRcHeavyDegree) {                 // a hub: left to the whole workgroup below
+                const int q = atomicAdd(&heavy_n, 1);
+                heavy_lo[q] = lo; heavy_hi[q] = hi; heavy_delta[q] = delta;
+            } else {
+                for (int k = lo; k < hi; ++k) {
+                    const uint32_t x = adj[k];
+                    const long long add = (x >> 31) ? -delta : delta;
+                    atomicAdd(reinterpret_cast<unsigned long long *>(rc + (x & 0x7FFFFFFFu)), (unsigned long long)add);
+                }
             }
         }
     }
     if (i < n_st) {
         const int a = arcs[i] - base;
         if ((unsigned)a < (unsigned)count_padded) state[a] = (int8_t)states[i];
+    }
+    __syncthreads();
+    for (int q = 0; q < heavy_n; ++q) {
+        const int64_t delta = heavy_delta[q];
+        for (int k = heavy_lo[q] + tid; k < heavy_hi[q]; k += kThreads) {
+            const uint32_t x = adj[k];
+            const long long add = (x >> 31) ? -delta : delta;
+            atomicAdd(reinterpret_cast<unsigned long long *>(rc + (x & 0x7FFFFFFFu)), (unsigned long long)add);
+        }
     }
 }
 

@@ -943,3 +943,38 @@ def test_candidate_cache_survives_the_wrap_of_its_epoch_counter(monkeypatch):
     assert np.array_equal(ns.trace(), tr_o), int(np.argmax(ns.trace()[: len(tr_o)] != tr_o[: len(ns.trace())]))
     e = ns.get_metrics()["engine"]
     assert e["candidates"] == 1 and e["host_decided"] > e["resident_requests"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [pytest.param("rc", id="rc-layout"), pytest.param("rc-resident", id="rc-resident-lds"), pytest.param("rc-stream", id="rc-resident-stream")])
+def test_rc_layout_with_hub_nodes(mode, monkeypatch):
+    """RC layout on a graph with hubs (two nodes carry a third of the arc ends): a hub's arc list is far longer than what rides in a scan's
+    arguments, and in update_rc_kernel it is walked by a whole workgroup instead of one thread."""
+    flags = _mode_flags(mode, monkeypatch)
+    rng = np.random.default_rng(919)
+    m_s, n = 90_007, 12_000
+    a = _random_soa(rng, m_s, n, 9, 40, extra=0)
+    hub = rng.random(m_s)
+    a["src"][hub < 0.2] = 0
+    a["tgt"][(hub >= 0.2) & (hub < 0.33)] = 7
+    eng = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible, optimized=True, flags=flags)
+    eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+    for it in range(12):
+        f, e, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+        assert eng.find_entering() == (f, e, c), it
+        k = int(rng.choice([1, 3, 40, 700, 3000]))
+        nodes = rng.choice(np.arange(8, n), size=k, replace=False).astype(np.int32)
+        if it % 2 == 0:
+            nodes[0] = 0                      # the hub moves with the list
+        if it % 3 == 0 and k > 1:
+            nodes[1] = 7
+        sigma = int(rng.integers(-6, 7))
+        a["pi"][nodes] += sigma
+        eng.shift_potential(nodes, a["pi"][nodes], sigma)
+        arcs = rng.choice(m_s, size=2, replace=False).astype(np.int32); vals = rng.integers(-1, 2, 2).astype(np.int8)
+        a["state"][arcs] = vals
+        eng.patch_state(arcs, vals)
+    f, e, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+    assert eng.find_entering() == (f, e, c)
+    assert np.array_equal(eng.download_pi(), a["pi"]) and np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
+    assert eng.stats()["rc_layout"] == 1
