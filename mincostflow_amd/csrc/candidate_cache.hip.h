@@ -1,0 +1,303 @@
+// candidate_cache.hip.h -- host side of the exact candidate cache of the resident engine (included by engine.hip only, inside its anonymous
+// namespace, after the resident-grid helpers it posts and collects with).  DESIGN.md section 3.4.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------ candidate cache
+// Best Eligible picks argmin (c, arc) over ALL search arcs with the CURRENT potentials (NS.cs:1644-1667).  A pivot changes the
+// potentials of one subtree and one or two states, so only arcs that touch those nodes change their key; every other arc keeps the key
+// the last device search saw.  A device search returns a sorted candidate list that is COMPLETE below a threshold (every eligible arc
+// with a smaller key is on it) as of the moment it was posted (its epoch).  The host keeps
+//   * the list, and for every node / arc the epoch of its last change: a list entry is CLEAN when nothing of it changed after the list's epoch;
+//   * a min-heap with the current keys of all arcs touched since (re-evaluated from the host mirrors when they are touched; at most
+//     cand_max_nodes nodes' adjacency per pivot -- a bigger subtree is not evaluated here, the device searches instead).
+// Then, exactly:   min over untouched arcs = first clean list entry (all unlisted untouched arcs lie above the threshold)
+//                  min over touched arcs   = top of the heap
+// and the entering arc is the smaller of the two -- the reference's pivot, arc for arc (every parity test runs with the cache on and off).
+// The list is refreshed ASYNCHRONOUSLY: when it runs low the next device search is posted while the host keeps answering from the current
+// list; its answer is installed when it has arrived.  The host only waits for the device when it cannot decide: after a big subtree
+// moved, or when the list ran out above the threshold.
+constexpr int64_t kCandMaxPivotDegree = 1024;   // adjacency entries re-evaluated per pivot at most
+constexpr int kCandMaxAvgDegree = 24;           // denser graphs: a single moved node already touches too many arcs
+
+inline const int64_t *cand_pi(const mcf_engine *e) { return e->ext_pi ? e->ext_pi : e->pi.data(); }
+inline bool cand_key_less(const mcf_engine::CandKey &a, const mcf_engine::CandKey &b) { return a.c < b.c || (a.c == b.c && a.p < b.p); }
+struct CandHeapAfter {        // std::*_heap keep the LARGEST on top: order by "comes later"
+    bool operator()(const mcf_engine::HeapEnt &a, const mcf_engine::HeapEnt &b) const { return b.c < a.c || (b.c == a.c && b.p < a.p); }
+};
+
+// a potential / state change reported by the caller (the mirrors e->pi / e->h_state already hold the new value)
+inline void cand_note_node(mcf_engine *e, int u)
+{
+    if (e->node_at[u] != e->cand_now) {
+        e->node_at[u] = e->cand_now;
+        e->sync_nodes.push_back(u);
+        if (!e->pivot_overflow) {
+            e->pivot_nodes.push_back(u);
+            e->pivot_degree += e->adj_start[u + 1] - e->adj_start[u];
+            if ((int)e->pivot_nodes.size() > e->cand_max_nodes || e->pivot_degree > kCandMaxPivotDegree) e->pivot_overflow = true;
+        }
+    }
+}
+inline void cand_note_arc(mcf_engine *e, int a)
+{
+    if (e->arc_at[a] != e->cand_now) { e->arc_at[a] = e->cand_now; e->sync_arcs.push_back(a); e->pivot_arcs.push_back(a); }
+}
+// Long lists (a big subtree): nothing will be evaluated here -- the device searches next, and a list of its epoch or later makes the
+// touched nodes' stamps irrelevant (cand_decide) -- so the list is taken over as it is, without a look at its nodes.
+inline int cand_note_nodes_blind(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values, bool continuation)
+{
+    e->pivot_overflow = true;
+    if (e->blind_count == 0) { e->blind_epoch = e->cand_now; e->blind_sets = 0; }
+    if (!continuation) {
+        e->blind_sets += 1;
+        // a second list may repeat nodes of the first with other values: whatever of the first has travelled is applied again, in order
+        if (e->blind_sets > 1 && e->stream_lines > 0) { const int rc = resident_stop(e); if (rc) return rc; }
+    }
+    e->pend_node.insert(e->pend_node.end(), nodes, nodes + count);
+    e->pend_val.insert(e->pend_val.end(), values, values + count);
+    e->blind_count = e->pend_node.size();
+    // a list refresh that has arrived meanwhile is taken in now, so that this list can start travelling
+    if (e->async_posted && cand_records_ready(e, 0)) { const int rc = cand_collect(e, e->async_at); if (rc) return rc; }
+    resident_stream(e);
+    return MCF_OK;
+}
+
+inline void cand_push(mcf_engine *e, int a)
+{
+    const uint32_t stamp = ++e->arc_stamp[a];
+    const int st = e->h_state[a];
+    if (st == 0) return;
+    const int64_t *pi = cand_pi(e);
+    const int64_t d = e->h_cost[a] + pi[e->h_src[a]] - pi[e->h_tgt[a]];
+    const int64_t rc = st > 0 ? d : -d;
+    if (rc >= 0) return;
+    e->heap.push_back(mcf_engine::HeapEnt{rc, (uint32_t)a, stamp});
+    std::push_heap(e->heap.begin(), e->heap.end(), CandHeapAfter());
+}
+
+// all changes of the pivot are in: bring the heap up to date (or note that it is not)
+void cand_absorb_pivot(mcf_engine *e)
+{
+    if (e->pivot_overflow) {
+        e->heap_gap = e->cand_now;
+        // arcs next to the moved nodes keep heap entries of older versions: they must not be taken for current ones
+        // (entries are only trusted for snapshots taken at or after heap_gap, and those know the arcs' present keys -- see cand_decide)
+    } else {
+        const int64_t *pi = cand_pi(e);
+        for (int u : e->pivot_nodes) {
+            const int64_t pu = pi[u];
+            // everything an evaluation needs sits in the entry except the other end's potential and the arc's version counter; an arc
+            // between two moved nodes is evaluated twice (the second entry outdates the first), which is cheaper than remembering it
+            for (int i = e->adj_start[u], hi = e->adj_start[u + 1]; i < hi; ++i) {
+                const mcf_engine::AdjEnt &x = e->adj[i];
+                const uint32_t stamp = ++e->arc_stamp[x.arc];
+                const int st = (int)((x.other >> 29) & 3u) - 1;
+                if (st == 0) continue;
+                const int64_t po = pi[x.other & 0x1FFFFFFFu];
+                const int64_t d = (x.other >> 31) ? x.cost + po - pu : x.cost + pu - po;
+                const int64_t rc = st > 0 ? d : -d;
+                if (rc >= 0) continue;
+                e->heap.push_back(mcf_engine::HeapEnt{rc, (uint32_t)x.arc, stamp});
+                std::push_heap(e->heap.begin(), e->heap.end(), CandHeapAfter());
+            }
+        }
+        for (int a : e->pivot_arcs) cand_push(e, a);
+    }
+    if (e->pivot_overflow) for (int a : e->pivot_arcs) { ++e->arc_stamp[a]; }     // their old entries are stale either way
+    e->pivot_nodes.clear();
+    e->pivot_arcs.clear();
+    e->pivot_degree = 0;
+    e->pivot_overflow = false;
+    if (e->heap.size() > (1u << 18)) {          // drop what lazy deletion left behind
+        size_t keep = 0;
+        for (size_t i = 0; i < e->heap.size(); ++i)
+            if (e->heap[i].stamp == e->arc_stamp[e->heap[i].p]) e->heap[keep++] = e->heap[i];
+        e->heap.resize(keep);
+        std::make_heap(e->heap.begin(), e->heap.end(), CandHeapAfter());
+    }
+}
+
+// true: *k holds the entering arc (or "none": the scan would find nothing either) without asking the device
+bool cand_decide(mcf_engine *e, Key *k)
+{
+    // the heap knows every change after snap_at only if none of them was skipped (heap_gap) -- and after a gap the entries of the arcs
+    // next to the skipped nodes are outdated without being marked so; a snapshot at or after the gap makes all of that irrelevant:
+    // an arc touched at or before snap_at is judged by the list (or lies above the threshold), whatever the heap says about it
+    if (!e->cand_valid || e->snap_at < e->heap_gap) return false;
+    mcf_engine::CandKey best_d{0, kNone};
+    while (!e->heap.empty()) {
+        const mcf_engine::HeapEnt &t = e->heap.front();
+        const uint32_t a = t.p;
+        // current version, and touched after the snapshot (an arc last touched before it is the list's business)
+        const bool fresh = t.stamp == e->arc_stamp[a];
+        const bool after = e->arc_at[a] > e->snap_at || e->node_at[e->h_src[a]] > e->snap_at || e->node_at[e->h_tgt[a]] > e->snap_at;
+        if (fresh && after) { best_d = mcf_engine::CandKey{t.c, a}; break; }
+        std::pop_heap(e->heap.begin(), e->heap.end(), CandHeapAfter());
+        e->heap.pop_back();
+    }
+    while (e->cand_ptr < e->cand_list.size()) {
+        const uint32_t a = e->cand_list[e->cand_ptr].p;
+        if (e->arc_at[a] <= e->snap_at && e->node_at[e->cand_ends[2 * e->cand_ptr]] <= e->snap_at && e->node_at[e->cand_ends[2 * e->cand_ptr + 1]] <= e->snap_at) break;
+        e->cand_ptr++;
+    }
+    mcf_engine::CandKey win{0, kNone};
+    if (e->cand_ptr < e->cand_list.size()) {
+        win = e->cand_list[e->cand_ptr];
+        if (best_d.p != kNone && cand_key_less(best_d, win)) win = best_d;
+    } else if (e->cand_thr.p == kNone) {
+        win = best_d;                                   // the list was complete: nothing untouched is left
+    } else if (best_d.p != kNone && cand_key_less(best_d, e->cand_thr)) {
+        win = best_d;                                   // everything untouched and unlisted lies above the threshold
+    } else {
+        return false;
+    }
+    k->c = win.p == kNone ? 0 : win.c;
+    k->r = 0;
+    k->p = win.p;
+    return true;
+}
+
+// the request for a device search: every node / arc changed since the last request, with their CURRENT values
+int cand_build_patches(mcf_engine *e)
+{
+    // Every entry of a node must carry the same value (the device applies a list in no particular order).  Entries gathered here do (they
+    // are read from the mirror now); the big lists do when they are ONE pivot's list of this very epoch (its pieces repeat no node
+    // and nothing can have changed since) -- otherwise their values are read again too, and nothing of them may have travelled yet.
+    const int64_t *pi = cand_pi(e);
+    const size_t n_b = e->blind_count, n_s = e->sync_nodes.size();
+    const bool blind_current = n_b == 0 || (e->blind_epoch == e->cand_now && e->blind_sets <= 1);
+    const bool squeeze = (int64_t)n_b + (int64_t)n_s > e->patch_capacity;            // lists may repeat nodes: squeeze the repeats out
+    if ((!blind_current || squeeze) && e->stream_lines > 0) { const int rc = resident_stop(e); if (rc) return rc; }
+    if (squeeze) {
+        e->pend_node.insert(e->pend_node.end(), e->sync_nodes.begin(), e->sync_nodes.end());
+        std::sort(e->pend_node.begin(), e->pend_node.end());
+        e->pend_node.erase(std::unique(e->pend_node.begin(), e->pend_node.end()), e->pend_node.end());
+        e->pend_val.resize(e->pend_node.size());
+        for (size_t i = 0; i < e->pend_node.size(); ++i) e->pend_val[i] = pi[e->pend_node[i]];
+    } else {
+        if (!blind_current) for (size_t i = 0; i < n_b; ++i) e->pend_val[i] = pi[e->pend_node[i]];
+        e->pend_node.resize(n_b + n_s);
+        e->pend_val.resize(n_b + n_s);
+        for (size_t i = 0; i < n_s; ++i) { e->pend_node[n_b + i] = e->sync_nodes[i]; e->pend_val[n_b + i] = pi[e->sync_nodes[i]]; }
+    }
+    e->pend_arc.assign(e->sync_arcs.begin(), e->sync_arcs.end());
+    e->pend_state.resize(e->pend_arc.size());
+    for (size_t i = 0; i < e->pend_arc.size(); ++i) e->pend_state[i] = e->h_state[e->pend_arc[i]];
+    e->sync_nodes.clear();
+    e->sync_arcs.clear();
+    e->blind_count = 0;
+    return MCF_OK;
+}
+
+bool cand_records_ready(const mcf_engine *e, int g)
+{
+    const volatile Slot *rec = e->h_slots + (size_t)g * kCandRecords;
+    for (int r = 0; r < kCandRecords; ++r) { const int64_t c = rec[r].c; const uint32_t q = rec[r].p; if (rec[r].tag != record_tag(e->seq, c, q)) return false; }
+    return true;
+}
+
+// wait for the candidate records of request e->seq and install them as the list of epoch `at`
+int cand_collect(mcf_engine *e, uint32_t at)
+{
+    const double t0 = (double)__rdtsc();
+    double t0_wall = 0;
+    const volatile Slot *slots = e->h_slots;
+    e->cand_list.clear();
+    e->cand_thr = mcf_engine::CandKey{0, kNone};
+    for (int g = 0; g < e->res_grid; ++g) {
+        const volatile Slot *rec = slots + (size_t)g * kCandRecords;
+        uint64_t spins = 0;
+        while (!cand_records_ready(e, g)) {
+            _mm_pause();
+            if (e->resident_running && (spins & 0xFFF) == 0xFFF && ((const volatile uint32_t *)e->h_exit)[0] != 0) {
+                int rc = resident_restart(e);
+                if (rc) return rc;
+            }
+            if ((++spins & 0xFFFFF) == 0) {
+                const hipError_t q = hipStreamQuery(e->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return mcf::fail(MCF_ERR_HIP, "resident grid failed: %s", hipGetErrorString(q));
+                if (t0_wall == 0) t0_wall = mcf::now_ns();
+                else if (mcf::now_ns() - t0_wall > 20e9) return mcf::fail(MCF_ERR_TIMEOUT, "no answer from the device after 20 s (workgroup %d of %d)", g, e->res_grid);
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (int r = 0; r < kCandPerGroup; ++r)
+            if (rec[r].p != kNone) e->cand_list.push_back(mcf_engine::CandKey{rec[r].c, rec[r].p});
+        if (rec[kCandPerGroup].p != kNone) {
+            const mcf_engine::CandKey t{rec[kCandPerGroup].c, rec[kCandPerGroup].p};
+            if (e->cand_thr.p == kNone || cand_key_less(t, e->cand_thr)) e->cand_thr = t;
+        }
+    }
+    e->wait_ticks += (double)__rdtsc() - t0;
+    if (e->cand_thr.p != kNone) {      // keep only what is provably complete: keys below the smallest unreported key
+        size_t keep = 0;
+        for (size_t i = 0; i < e->cand_list.size(); ++i)
+            if (cand_key_less(e->cand_list[i], e->cand_thr)) e->cand_list[keep++] = e->cand_list[i];
+        e->cand_list.resize(keep);
+    }
+    std::sort(e->cand_list.begin(), e->cand_list.end(), cand_key_less);
+    e->cand_ends.resize(2 * e->cand_list.size());
+    for (size_t i = 0; i < e->cand_list.size(); ++i) { e->cand_ends[2 * i] = e->h_src[e->cand_list[i].p]; e->cand_ends[2 * i + 1] = e->h_tgt[e->cand_list[i].p]; }
+    e->cand_ptr = 0;
+    e->cand_valid = true;
+    e->snap_at = at;
+    e->async_posted = false;
+    e->tk_collect += (double)__rdtsc() - t0;
+    return MCF_OK;
+}
+
+// posts a device search that carries everything the device has not heard yet; its list will be of epoch cand_now
+int cand_post(mcf_engine *e)
+{
+    if (int rcb = cand_build_patches(e)) return rcb;
+    if ((int)e->pend_arc.size() > e->mailbox_max_st) {      // hundreds of pivots' worth of state writes: cannot happen between two requests, kept for safety
+        int rc = resident_stop(e);
+        if (!rc) rc = flush_pending(e);
+        if (rc) return rc;
+    }
+    e->prev_seq = e->seq;
+    e->seq += 1;
+    if (e->seq == 0) e->seq = 1;
+    int rc = resident_start(e, e->prev_seq);
+    if (rc) return rc;
+    resident_post(e, e->seq, 0u, true);
+    if (!e->pend_node.empty() || !e->pend_arc.empty()) e->st.inline_updates += 1;
+    e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
+    e->posted_at = e->cand_now;
+    e->st.arcs_scanned += e->end - e->begin;
+    return MCF_OK;
+}
+
+// the host mirrors' arc lists per node, with what a re-evaluation needs next to each other (upload, mcf_engine_patch_arcs)
+void cand_build_adjacency(mcf_engine *e)
+{
+    const int n = e->d.node_count, m_s = e->d.search_arc_num;
+    const int32_t *source = e->h_src.data(), *target = e->h_tgt.data();
+    e->adj_start.assign(n + 1, 0);
+    for (int a = 0; a < m_s; ++a) { e->adj_start[source[a] + 1]++; if (target[a] != source[a]) e->adj_start[target[a] + 1]++; }
+    for (int u = 0; u < n; ++u) e->adj_start[u + 1] += e->adj_start[u];
+    e->adj.assign(e->adj_start[n], mcf_engine::AdjEnt{0, 0u, 0});
+    e->adj_pos.assign((size_t)2 * m_s, -1);
+    std::vector<int32_t> fill(e->adj_start.begin(), e->adj_start.end() - 1);
+    for (int a = 0; a < m_s; ++a) {
+        const uint32_t st_bits = (uint32_t)(e->h_state[a] + 1) << 29;
+        e->adj_pos[2 * (size_t)a] = fill[source[a]];
+        e->adj[fill[source[a]]++] = mcf_engine::AdjEnt{a, (uint32_t)target[a] | st_bits, e->h_cost[a]};
+        if (target[a] != source[a]) {
+            e->adj_pos[2 * (size_t)a + 1] = fill[target[a]];
+            e->adj[fill[target[a]]++] = mcf_engine::AdjEnt{a, (uint32_t)source[a] | st_bits | 0x80000000u, e->h_cost[a]};
+        }
+    }
+}
+
+// forgets the list and the heap (upload, or the device state was changed behind the cache's back)
+void cand_reset(mcf_engine *e)
+{
+    e->cand_valid = false;
+    e->cand_list.clear();
+    e->cand_ptr = 0;
+    e->heap.clear();
+    e->pivot_nodes.clear(); e->pivot_arcs.clear(); e->pivot_degree = 0; e->pivot_overflow = false;
+    e->heap_gap = e->cand_now;
+}
+
