@@ -8,11 +8,13 @@
 //   a4        potential update over the moved subtree                                          (NS.cs:1185-1209)
 //   a5        the one or two State[] writes of ChangeFlow                                      (NS.cs:1030-1039)
 //
-// Default mode: ONE resident grid per solve; requests (sequence number, next_arc, the previous pivot's patches as final values) are
-// written by the host through the PCIe BAR into a mailbox in fine-grained VRAM, every workgroup applies all patches itself before it
-// reads anything, scans the arcs it keeps in registers and answers.  Dispatch mode (sharded engines, timing flags, no host-writable
-// VRAM, instances too large for registers / LDS): one scan dispatch per search with the patches in its kernel arguments; large sparse
-// Best-Eligible instances are stored in bucketed order (build at upload, pos_of / d_orig).  See DESIGN.md sections 2 and 3.
+// Default mode: ONE resident grid per solve; requests (sequence number, next_arc, block size, the previous pivot's patches as final values)
+// are written by the host through the PCIe BAR into a mailbox in fine-grained VRAM, every workgroup applies all patches itself before it
+// reads anything, scans the arcs it keeps in registers and answers; for Best Eligible on sparse graphs most searches are answered on the
+// host from the last answer's candidate list (candidate_cache.hip.h).  Arcs that fit neither registers nor LDS use the RC layout: reduced
+// costs kept per arc, shifted by the moved nodes' arc lists, scanned without gathers by a resident grid of its own or one dispatch per
+// search.  Dispatch mode (RCCL-sharded engines, timing flags, no host-writable VRAM, no free resident slot): one scan dispatch per search
+// with the patches in its kernel arguments.  See DESIGN.md sections 2 and 3.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <hsa/hsa.h>
