@@ -619,8 +619,8 @@ __device__ __forceinline__ void store_record_system(Slot *slot, int64_t c, uint3
 // from the candidate list as long as the answer provably is on it (mcf_engine.cand_* in the host code) -- same pivots, fewer
 // round trips.  Per thread: best and second best of its 4 arcs; per wave: two butterflies give the wave's best and its exact
 // second best; thread 0 keeps the 4 best of the 16 wave winners and folds everything else into the threshold.
-constexpr int kCandPerGroup = 4;
-constexpr int kCandRecords = 8;        // record stride per workgroup in candidate mode: 4 candidates, 1 threshold, 3 unused
+constexpr int kCandPerGroup = 3;
+constexpr int kCandRecords = 4;        // records per workgroup in candidate mode: 3 candidates + the threshold = one whole 64-byte line
 
 template <typename T>
 __device__ __forceinline__ void eval_tile_best2(const TileData<T> &d, const T *pi, int e0, int64_t &c1, uint32_t &p1, int64_t &c2, uint32_t &p2,
