@@ -614,11 +614,11 @@ __device__ __forceinline__ void store_record_system(Slot *slot, int64_t c, uint3
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(slot), "v"(out) : "memory");
 }
 
-// Best Eligible with candidates (CAND): besides its best arc a workgroup reports up to three more candidates and a THRESHOLD
+// Best Eligible with candidates (CAND): besides its best arc a workgroup reports up to two more candidates and a THRESHOLD
 // = the smallest key among all of its eligible arcs that it does NOT report.  The host can then serve the following pivots
 // from the candidate list as long as the answer provably is on it (mcf_engine.cand_* in the host code) -- same pivots, fewer
 // round trips.  Per thread: best and second best of its 4 arcs; per wave: two butterflies give the wave's best and its exact
-// second best; thread 0 keeps the 4 best of the 16 wave winners and folds everything else into the threshold.
+// second best; thread 0 keeps the kCandPerGroup best of the wave winners and folds everything else into the threshold.
 constexpr int kCandPerGroup = 3;
 constexpr int kCandRecords = 4;        // records per workgroup in candidate mode: 3 candidates + the threshold = one whole 64-byte line
 
@@ -690,7 +690,7 @@ __device__ __forceinline__ void publish_candidates(int64_t c1, uint32_t p1, int6
         for (int k = 0; k < kCandPerGroup; ++k) { out_rec[k].c = kc[k]; out_rec[k].p = kp[k]; }
         for (int k = kCandPerGroup; k < kCandRecords; ++k) { out_rec[k].c = tc; out_rec[k].p = tp; }     // threshold, repeated to fill the line
     }
-    // eight lanes of wave 0 write the eight records = two whole 64-byte lines (same wave as thread 0: LDS order is program order)
+    // kCandRecords lanes of wave 0 write the records = one whole 64-byte line (same wave as thread 0: LDS order is program order)
     if (tid < kCandRecords) store_record_system(slots + (size_t)blockIdx.x * kCandRecords + tid, out_rec[tid].c, out_rec[tid].p, tag);
 }
 
