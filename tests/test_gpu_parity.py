@@ -978,3 +978,23 @@ def test_rc_layout_with_hub_nodes(mode, monkeypatch):
     assert eng.find_entering() == (f, e, c)
     assert np.array_equal(eng.download_pi(), a["pi"]) and np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
     assert eng.stats()["rc_layout"] == 1
+
+
+@pytest.mark.gpu
+def test_headline_workload_is_pivot_for_pivot_the_oracle():
+    """BASELINE config 3 -- the bench's headline workload -- at full size, default engine (resident grid + candidate cache): all 190 580 entering
+    arcs equal the CPU oracle's Best-Eligible pivots (about a minute of one core), and so do cost, flows and potentials."""
+    g = M.netgen_like(13502460, 100_000, 300_000, 316, 316)
+    p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
+    ns = M.NetworkSimplex.from_problem(g).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).set_device(0, 64).record_trace(1 << 20)
+    assert ns.solve() == M.SolverStatus.Optimal
+    o = O.Oracle(p, O.SEM_CSHARP_OPT, O.RULE_BEST)
+    st_o, tr_o = o.solve(trace_cap=1 << 20)
+    assert st_o == O.OPTIMAL
+    tr = ns.trace()
+    assert len(tr) == len(tr_o) == o.n_pivots
+    assert np.array_equal(tr, tr_o), int(np.argmax(tr != tr_o))
+    assert ns.get_total_cost() == o.total_cost
+    assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
+    e = ns.get_metrics()["engine"]
+    assert e["candidates"] == 1 and e["host_decided"] > 5 * e["resident_requests"]
