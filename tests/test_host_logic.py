@@ -322,3 +322,35 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(t) for t in (L.EngineStats, L.NsMetrics, L.EngineDesc, L.BlockConfig, L.Candidate, L.Validation)]
     assert got == want
+
+
+def test_new_entry_points_validate_their_arguments():
+    """Argument and call-order errors of the round-2 entry points (no GPU involved): the reference's ArgumentException / InvalidOperationException cases."""
+    lib = L.lib()
+    p = load("transport_2x3")
+    ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
+    for call in (lambda: ns.set_sharding_host("no-slash", 0, 2), lambda: ns.set_sharding_host("/x", 2, 2), lambda: ns.set_shard_group([]),
+                 lambda: ns.set_shard_group([0, -1]), lambda: ns.tree()):
+        with pytest.raises(M.McfError) as ei:
+            call()
+        assert ei.value.code in (L.ERR_INVALID, L.ERR_STATE)
+    assert lib.mcf_ns_set_optimization_config(ns._h, None) == L.ERR_INVALID            # ArgumentNullException, NetworkSimplex.cs:559
+    assert ns.begin() == 0
+    t = ns.tree()
+    assert len(t["parent"]) == p.n + 1 and t["parent"][p.n] == -1 and (t["succ_num"][p.n] == p.n + 1)
+    c = M.block_config()
+    b, d = C.c_int32(), C.c_int32()
+    assert lib.mcf_block_initial_size(None, 10, 10, C.byref(b), C.byref(d)) == L.ERR_INVALID
+    assert lib.mcf_block_initial_size(C.byref(c), -1, 10, C.byref(b), C.byref(d)) == L.ERR_INVALID
+    assert lib.mcf_block_adapt(C.byref(c), 25, 100, None, None) == L.ERR_INVALID
+    with pytest.raises(M.McfError):
+        M.auto_block_config(2, [0, 5], [1, 0])                                           # end point outside the node range
+    # density of an empty search range over no nodes: C#'s 0.0 / 0 is NaN, 'NaN > 10' is false
+    small = M.block_config(flags=M.OPT_SMALL_BLOCKS_FOR_DENSE)
+    L.check(lib.mcf_block_initial_size(C.byref(small), 0, 0, C.byref(b), C.byref(d)))
+    assert (b.value, d.value) == (25, 25)
+    # the adaptive rule leaves the size alone without its flag
+    counters = (C.c_int32 * 2)(0, 0)
+    b.value = 77
+    L.check(lib.mcf_block_adapt(C.byref(c), 25, 1000, C.byref(b), counters))
+    assert b.value == 77 and list(counters) == [0, 0]
