@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--no-validator", action="store_true", help="skip the SolutionValidator measurement")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact config-2 / config-4 blocks")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline sample")
-    ap.add_argument("--sharded-pivots", type=int, default=-1, help="N>1: pivots of config 5 timed with the arcs sharded over the ranks (-1 = 5000 when N > 1, 0 = skip)")
+    ap.add_argument("--sharded-pivots", type=int, default=-1, help="N>1: pivots of config 5 timed with the arcs sharded over the ranks (-1 = 5000 when N > 1, 2000 with one rank; 0 = skip)")
     ap.add_argument("--dispatch", action="store_true", help="one scan dispatch per search instead of the resident grid")
     ap.add_argument("--concurrent", type=int, default=4, help="extra measurement: this many independent solves at once on the GPU (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo: rehearsals on one GPU)")
@@ -156,6 +156,8 @@ def sharded_leg(M, torch, dist, args, rank, world, dev, barrier, red_dev):
 
     out = {"workload": "NETGEN-like 1M nodes / 8M arcs, Best Eligible, int64, arcs sharded over the ranks (contiguous ranges, potentials replicated)",
            "ranks": world, "pivots_timed": P, "search_arcs": 9_000_000, "variants": {}}
+    if world == 1:
+        out["note"] = "a world of ONE rank: the sharded path's code (shard engine, exchange, MINLOC, RCCL all-gather) runs on this box, there is nothing to scale"
     port = os.environ.get("MASTER_PORT", "0")
     sec, m5, tr_host = run(lambda ns: ns.set_sharding_host(f"/mcf_bench_{port}_{os.getppid()}", rank, world))
     out["variants"]["host_exchange"] = {"exchange": "16-byte records through POSIX shared memory (mcf_exchange_all_gather), resident or dispatch scan per shard",
@@ -426,7 +428,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to label a {world}-rank run as {args.gpus} GPUs")
     if args.sharded_pivots < 0:
-        args.sharded_pivots = 5000 if world > 1 else 0
+        args.sharded_pivots = 5000 if world > 1 else 2000      # one rank: the same legs with a world of 1 (the code paths on this box, not a scaling figure)
 
     import torch
     import mincostflow_amd as M
