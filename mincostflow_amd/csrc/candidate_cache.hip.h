@@ -28,6 +28,7 @@ struct CandHeapAfter {        // std::*_heap keep the LARGEST on top: order by "
 // a potential / state change reported by the caller (the mirrors e->pi / e->h_state already hold the new value)
 inline void cand_note_node(mcf_engine *e, int u)
 {
+    if (e->blind_count > 0 && e->blind_epoch == e->cand_now) e->blind_sets = 2;      // may repeat a node of the big list with a newer value: that list's values are read again
     if (e->node_at[u] != e->cand_now) {
         e->node_at[u] = e->cand_now;
         e->sync_nodes.push_back(u);

@@ -998,3 +998,28 @@ def test_headline_workload_is_pivot_for_pivot_the_oracle():
     assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
     e = ns.get_metrics()["engine"]
     assert e["candidates"] == 1 and e["host_decided"] > 5 * e["resident_requests"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [pytest.param(0, id="candidates"), pytest.param(M.ENGINE_NO_CANDIDATES, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch")])
+def test_overlapping_potential_lists_between_two_searches(mode):
+    """Two mcf_engine_set_potential calls between two searches, the second repeating nodes of the first with newer values (a big list then
+    a small one, two big ones, a small one then a big one): the later value wins in every engine mode."""
+    rng = np.random.default_rng(4711)
+    m_s, n = 150_001, 40_000
+    a = _random_soa(rng, m_s, n, 5, 15)
+    eng = M.PivotEngine(n, len(a["src"]), m_s, rule=M.PivotRule.BestEligible, optimized=True, flags=mode)
+    eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+    for it, (k1, k2) in enumerate([(6000, 3), (5000, 7000), (4, 6000), (2, 2), (6000, 40), (9000, 9000)]):
+        f, e, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+        assert eng.find_entering() == (f, e, c), it
+        first = rng.choice(n, size=k1, replace=False).astype(np.int32)
+        a["pi"][first] -= 3
+        eng.set_potential(first, a["pi"][first])
+        second = np.concatenate([first[: min(k1, k2) // 2 + 1], rng.choice(n, size=k2, replace=False).astype(np.int32)])
+        second = np.unique(second).astype(np.int32)
+        a["pi"][second] += 5
+        eng.set_potential(second, a["pi"][second])
+    f, e, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+    assert eng.find_entering() == (f, e, c)
+    assert np.array_equal(eng.download_pi(), a["pi"])
