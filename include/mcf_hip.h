@@ -114,8 +114,9 @@ typedef struct mcf_engine_desc {
 #define MCF_ENGINE_SHARE_DEVICE 64        /* several engines use this device at once (independent solves): keep the resident grid's register
                                              and LDS footprint small so that their grids are co-resident on every CU -- the grid then gathers
                                              the potentials for every request instead of keeping them in registers (~0.5 us per search) */
-#define MCF_ENGINE_DISPATCH 16            /* one scan dispatch per search.  Also what an engine falls back to when it is sharded, when
-                                             kernel timing flags are set, or when the platform has no host-writable VRAM.
+#define MCF_ENGINE_DISPATCH 16            /* one scan dispatch per search.  Also what an engine falls back to when it exchanges over RCCL
+                                             (mcf_engine_comm_init), when kernel timing flags are set, when the platform has no host-writable
+                                             VRAM, or while the device's resident slots (GPU_MAX_HW_QUEUES per process, 4) are all taken.
                                              The environment variable MCF_HIP_RESIDENT=0/1 overrides the choice. */
 
 /* The part of OptimizationConfig (Algorithms/OptimizationTypes.cs:9-38) that the plain BlockSearchPivot consumes

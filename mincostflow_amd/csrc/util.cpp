@@ -106,7 +106,7 @@ int mcf_block_config_auto(mcf_block_config *c, int32_t n, int32_t m, const int32
     c->flags = flags;
     return MCF_OK;
 }
-const char *mcf_version(void) { return "mcf_hip 0.1 (gfx950)"; }
+const char *mcf_version(void) { return "mcf_hip 0.2 (gfx950)"; }
 
 
 // BlockSearchPivot constructor, NS.cs:1304-1336
