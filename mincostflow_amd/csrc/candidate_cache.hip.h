@@ -26,8 +26,12 @@ struct CandHeapAfter {        // std::*_heap keep the LARGEST on top: order by "
 };
 
 // a potential / state change reported by the caller (the mirrors e->pi / e->h_state already hold the new value)
-inline void cand_note_node(mcf_engine *e, int u)
+inline void cand_note_node(mcf_engine *e, int u, bool sigma_known = false, int64_t sigma = 0)
 {
+    if (e->rc_mode) {            // the RC layout's resident grid takes {node, shift} entries: one per occurrence (shifts add up)
+        if (sigma_known) e->rc_sync.push_back(mcf_engine::NodeShift{u, sigma});
+        else e->rc_shift_unknown = true;
+    }
     if (e->blind_count > 0 && e->blind_epoch == e->cand_now) e->blind_sets = 2;      // may repeat a node of the big list with a newer value: that list's values are read again
     if (e->node_at[u] != e->cand_now) {
         e->node_at[u] = e->cand_now;
@@ -167,7 +171,8 @@ int cand_build_patches(mcf_engine *e)
     const int64_t *pi = cand_pi(e);
     const size_t n_b = e->blind_count, n_s = e->sync_nodes.size();
     const bool blind_current = n_b == 0 || (e->blind_epoch == e->cand_now && e->blind_sets <= 1);
-    const bool squeeze = (int64_t)n_b + (int64_t)n_s > e->patch_capacity;            // lists may repeat nodes: squeeze the repeats out
+    // lists may repeat nodes (the update kernels take that: same value every time): squeeze the repeats out when they do not fit
+    const bool squeeze = (int64_t)n_b + (int64_t)n_s > e->patch_capacity;
     if ((!blind_current || squeeze) && e->stream_lines > 0) { const int rc = resident_stop(e); if (rc) return rc; }
     if (squeeze) {
         e->pend_node.insert(e->pend_node.end(), e->sync_nodes.begin(), e->sync_nodes.end());
@@ -187,6 +192,8 @@ int cand_build_patches(mcf_engine *e)
     e->sync_nodes.clear();
     e->sync_arcs.clear();
     e->blind_count = 0;
+    e->rc_sync.clear();
+    e->rc_shift_unknown = false;
     return MCF_OK;
 }
 
@@ -248,8 +255,48 @@ int cand_collect(mcf_engine *e, uint32_t at)
 }
 
 // posts a device search that carries everything the device has not heard yet; its list will be of epoch cand_now
+// RC layout: the request carries {node, shift} entries -- every occurrence of a node since the last request with the shift of that pivot (the
+// pivots' own small lists), plus this pivot's one big list with its common shift when it is short enough -- or, when that is not possible
+// (a shift that was not announced, too many entries), the grid is stopped and the values go through update_rc_kernel.
+int cand_post_rc(mcf_engine *e)
+{
+    const size_t n_b = e->blind_count, n_s = e->rc_sync.size();
+    const bool blind_ok = n_b == 0 || (e->pend_shift && e->blind_epoch == e->cand_now);      // shifts add up: a node may sit in both lists
+    const int64_t n_st = (int64_t)e->sync_arcs.size();
+    const bool fast = !e->rc_shift_unknown && blind_ok && (int64_t)(n_b + n_s) <= kRcResidentNodes && n_st <= e->mailbox_max_st &&
+                      (int64_t)(n_b + n_s > 1 ? n_b + n_s - 1 : 0) + (n_st > 2 ? n_st - 2 : 0) <= (int64_t)(kMailboxLines - 1) * kMailboxPatchesPerLine;
+    if (fast) {
+        e->pend_node.resize(n_b + n_s);
+        e->pend_val.resize(n_b + n_s);
+        for (size_t i = 0; i < n_b; ++i) e->pend_val[i] = e->pend_sigma;
+        for (size_t i = 0; i < n_s; ++i) { e->pend_node[n_b + i] = e->rc_sync[i].node; e->pend_val[n_b + i] = e->rc_sync[i].shift; }
+        e->pend_arc.assign(e->sync_arcs.begin(), e->sync_arcs.end());
+        e->pend_state.resize(e->pend_arc.size());
+        for (size_t i = 0; i < e->pend_arc.size(); ++i) e->pend_state[i] = e->h_state[e->pend_arc[i]];
+        e->sync_nodes.clear(); e->sync_arcs.clear(); e->rc_sync.clear();
+        e->blind_count = 0;
+    } else {
+        if (int rcb = cand_build_patches(e)) return rcb;        // {node, current value} lists
+        int rc = resident_stop(e);
+        if (!rc) rc = flush_pending(e);                          // update_rc_kernel: the device works the differences out itself
+        if (rc) return rc;
+    }
+    e->prev_seq = e->seq;
+    e->seq += 1;
+    if (e->seq == 0) e->seq = 1;
+    int rc = resident_start(e, e->prev_seq);
+    if (rc) return rc;
+    resident_post(e, e->seq, 0u, fast);
+    if (fast && (!e->pend_node.empty() || !e->pend_arc.empty())) e->st.inline_updates += 1;
+    e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
+    e->posted_at = e->cand_now;
+    e->st.arcs_scanned += e->end - e->begin;
+    return MCF_OK;
+}
+
 int cand_post(mcf_engine *e)
 {
+    if (e->rc_mode) return cand_post_rc(e);
     if (int rcb = cand_build_patches(e)) return rcb;
     if ((int)e->pend_arc.size() > e->mailbox_max_st) {      // hundreds of pivots' worth of state writes: cannot happen between two requests, kept for safety
         int rc = resident_stop(e);

@@ -193,6 +193,11 @@ struct mcf_engine {
     uint32_t blind_epoch = 0;                     // epoch of the first of those lists
     int blind_sets = 0;                           // lists in there that did not come as the continuation of another one
     bool cand_appending = false;                  // mcf_engine_append_potential is calling mcf_engine_set_potential
+    struct NodeShift { int32_t node; int64_t shift; };
+    std::vector<NodeShift> rc_sync;               // RC layout: the small lists' nodes with the shift of their pivot, one entry per occurrence
+    bool rc_shift_unknown = false;                // ... unless some change came without its shift (mcf_engine_set_potential): then values travel
+    bool call_shift_known = false;                // mcf_engine_shift_potential is calling: every node of the call moves by call_shift
+    int64_t call_shift = 0;
     std::vector<CandKey> cand_list;               // sorted; complete below cand_thr as of snap_at
     std::vector<int32_t> cand_ends;               // the end points of the listed arcs (2 per entry), looked up once when the list is installed
     size_t cand_ptr = 0;
@@ -913,7 +918,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
                     e->resident_reg = false;
                 }
                 e->cand_on = !(desc->flags & MCF_ENGINE_NO_CANDIDATES) && !(getenv("MCF_HIP_CANDIDATES") && getenv("MCF_HIP_CANDIDATES")[0] == '0') &&
-                             whole && e->resident_reg && desc->rule == MCF_RULE_BEST_ELIGIBLE && desc->node_count < (1 << 29) &&
+                             whole && (e->resident_reg || e->rc_mode) && desc->rule == MCF_RULE_BEST_ELIGIBLE && desc->node_count < (1 << 29) &&
                              2 * (int64_t)desc->search_arc_num <= (int64_t)kCandMaxAvgDegree * desc->node_count;
             }
         }
@@ -1058,6 +1063,7 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
         e->heap_gap = 0;
         e->async_posted = false;
         e->sync_nodes.clear(); e->sync_arcs.clear(); e->blind_count = 0;
+        e->rc_sync.clear(); e->rc_shift_unknown = false;
         cand_reset(e);
         e->heap_gap = 0;
         if (const char *u = getenv("MCF_HIP_CAND_EPOCH0")) { const unsigned long long v = strtoull(u, nullptr, 10); if (v >= 1 && v <= 0xFFFFFFFFull) e->cand_now = (uint32_t)v; }    // tests: start close to the wrap
@@ -1123,10 +1129,13 @@ int mcf_engine_update_potential(mcf_engine *e, int32_t count, const int32_t *nod
         if (count > e->cand_max_nodes || e->pivot_overflow) {
             std::vector<int64_t> vals((size_t)count);
             for (int i = 0; i < count; ++i) vals[i] = (e->pi[nodes[i]] += sigma);
+            const bool first = e->blind_count == 0;
             const int rcn = cand_note_nodes_blind(e, count, nodes, vals.data(), false);
             if (rcn) return rcn;
+            e->pend_shift = first;            // one list with one shift
+            e->pend_sigma = sigma;
         } else {
-            for (int i = 0; i < count; ++i) { e->pi[nodes[i]] += sigma; cand_note_node(e, nodes[i]); }
+            for (int i = 0; i < count; ++i) { e->pi[nodes[i]] += sigma; cand_note_node(e, nodes[i], true, sigma); }
         }
         e->st.potential_nodes += count;
         return MCF_OK;
@@ -1164,8 +1173,15 @@ int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes,
     }
     if (e->cand_on) {                 // the mirror stays authoritative in candidate mode
         if (!e->ext_pi) for (int i = 0; i < count; ++i) e->pi[nodes[i]] = values[i];      // bound potentials: the caller's array already holds them
-        if (count > e->cand_max_nodes || e->pivot_overflow) { const int rcn = cand_note_nodes_blind(e, count, nodes, values, e->cand_appending); if (rcn) return rcn; }
-        else for (int i = 0; i < count; ++i) cand_note_node(e, nodes[i]);
+        if (count > e->cand_max_nodes || e->pivot_overflow) {
+            const bool first = e->blind_count == 0;
+            const int rcn = cand_note_nodes_blind(e, count, nodes, values, e->cand_appending);
+            if (rcn) return rcn;
+            // the big list has ONE shift when every piece of it came with the same announced shift
+            e->pend_shift = e->call_shift_known && (first || (e->pend_shift && e->pend_sigma == e->call_shift));
+            e->pend_sigma = e->call_shift;
+        }
+        else for (int i = 0; i < count; ++i) cand_note_node(e, nodes[i], e->call_shift_known, e->call_shift);
         e->st.potential_nodes += count;
         return MCF_OK;
     }
@@ -1220,7 +1236,10 @@ int mcf_engine_shift_potential(mcf_engine *e, int32_t count, const int32_t *node
     if (!e) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_shift_potential: bad arguments");
     const bool first = e->pend_node.empty();
     const bool same = first || (e->pend_shift && e->pend_sigma == sigma);
+    e->call_shift_known = true;
+    e->call_shift = sigma;
     const int rc = mcf_engine_append_potential(e, count, nodes, values);
+    e->call_shift_known = false;
     if (rc) return rc;
     if (count > 0 && !e->cand_on) { e->pend_shift = same; e->pend_sigma = sigma; }
     return MCF_OK;

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(kThreads) void rc_init_kernel(const int32_t *src, c
 }
 
 // pi[node[i]] = value[i] and the change carried over to the node's arcs; state[arc[j]] = s[j].  One thread per node (a hub's arc list is
-// walked by its whole workgroup): the nodes of a list are distinct (the caller's contract), so every node's change is computed and applied exactly once.
+// walked by its whole workgroup): every node's change is computed and applied exactly once (a node named twice carries the same value both times).
 // adj: the shard's arcs incident to each node as local positions, bit 31 set when the node is the arc's TARGET.
 constexpr int kRcHeavyDegree = 512;         // a node with a longer arc list is shifted by its whole workgroup, not by one thread
 
@@ -466,8 +466,12 @@ __global__ __launch_bounds__(kThreads) void update_rc_kernel(T *pi, const int32_
     __syncthreads();
     if (i < n_pi) {
         const int u = nodes[i];
-        const int64_t delta = values[i] - (int64_t)pi[u];
-        pi[u] = (T)values[i];
+        // exchange, not read + write: a list of the candidate cache may name a node twice (with the same value) -- the second entry then
+        // finds the value in place and shifts nothing
+        int64_t old;
+        if (sizeof(T) == 4) old = (int64_t)atomicExch(reinterpret_cast<int *>(pi) + u, (int)values[i]);
+        else old = (int64_t)atomicExch(reinterpret_cast<unsigned long long *>(pi) + u, (unsigned long long)values[i]);
+        const int64_t delta = values[i] - old;
         if (delta != 0) {
             const int lo = adj_start[u], hi = adj_start[u + 1];
             if (hi - lo > kRcHeavyDegree) {                 // a hub: left to the whole workgroup below
@@ -959,6 +963,24 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
 constexpr int kRcWindow = 8192;                    // arcs per workgroup in LDS: 64 KB of reduced costs + 8 KB of states
 constexpr int kRcResidentNodes = 1 + 255 * kMailboxPatchesPerLine - 8;   // one chunk of entry lines, a few entries left for state patches
 
+// running best and second best (c, arc) of a thread's arcs in the RC layout (candidate variant of resident_rc_kernel, Best Eligible only)
+__device__ __forceinline__ void fold_rc_best2(uint32_t st4, const int64_t d[4], int e0, int64_t &c1, uint32_t &p1, int64_t &c2, uint32_t &p2)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int st = (int)(int8_t)(st4 >> (8 * j));
+        const int64_t rc = st > 0 ? d[j] : (st < 0 ? -d[j] : 0);
+        const uint32_t e = (uint32_t)(e0 + j);
+        const bool elig = rc < 0;
+        const bool b1 = elig && cand_less(rc, e, c1, p1);
+        const bool b2 = elig && !b1 && cand_less(rc, e, c2, p2);
+        c2 = b1 ? c1 : (b2 ? rc : c2);
+        p2 = b1 ? p1 : (b2 ? e : p2);
+        c1 = b1 ? rc : c1;
+        p1 = b1 ? e : p1;
+    }
+}
+
 struct ResidentRcParams {
     int8_t *state;
     int64_t *rc;
@@ -973,9 +995,10 @@ struct ResidentRcParams {
     int32_t narrow, max_pi, max_st, poll_replicas, poll_sleep;
 };
 
-template <int RULE, bool OPT, bool LD>
+template <int RULE, bool OPT, bool LD, bool CAND = false>
 __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const ResidentRcParams p)
 {
+    static_assert(!CAND || RULE == MCF_RULE_BEST_ELIGIBLE, "candidate lists serve Best Eligible");
     constexpr int kLines = kMailboxLines;                      // line 0 + one chunk of 255 entry lines
     constexpr int kNodesMax = 1280;
     __shared__ __attribute__((aligned(16))) uint32_t lm[kLines * 16];
@@ -1109,8 +1132,9 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
             }
             if (blockIdx.x == 0) {
                 for (int i = tid; i < n_pi; i += nt) {
-                    if (p.narrow) reinterpret_cast<int32_t *>(p.pi)[s_node[i]] += (int32_t)s_delta[i];
-                    else reinterpret_cast<int64_t *>(p.pi)[s_node[i]] += s_delta[i];
+                    // atomics: the candidate cache's requests carry several pivots' lists, a node may come more than once
+                    if (p.narrow) atomicAdd(reinterpret_cast<int32_t *>(p.pi) + s_node[i], (int32_t)s_delta[i]);
+                    else atomicAdd(reinterpret_cast<unsigned long long *>(p.pi) + s_node[i], (unsigned long long)s_delta[i]);
                 }
             }
         }
@@ -1137,11 +1161,14 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
         best.c = 0;
         best.r = kNone;
         best.p = kNone;
+        int64_t c1 = 0, c2 = 0;              // CAND: best and second best of this thread's arcs
+        uint32_t p1 = kNone, p2 = kNone;
         if (LD) {
             for (int i = tid * kArcsPerThread; i < p.window; i += nt * kArcsPerThread) {
                 const uint32_t st4 = *reinterpret_cast<const uint32_t *>(ls + i);
                 const int64_t d[4] = {ld[i], ld[i + 1], ld[i + 2], ld[i + 3]};
-                fold_rc<RULE, OPT>(st4, d, p.base + w_lo + i, p.m_s, next_arc, block_size, rstar, best);
+                if (CAND) fold_rc_best2(st4, d, p.base + w_lo + i, c1, p1, c2, p2);
+                else fold_rc<RULE, OPT>(st4, d, p.base + w_lo + i, p.m_s, next_arc, block_size, rstar, best);
             }
         } else {
             typedef long v2l __attribute__((ext_vector_type(2)));
@@ -1151,10 +1178,12 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
                 const v2l a = __builtin_nontemporal_load(reinterpret_cast<const v2l *>(p.rc + i0));
                 const v2l b = __builtin_nontemporal_load(reinterpret_cast<const v2l *>(p.rc + i0 + 2));
                 const int64_t d[4] = {a.x, a.y, b.x, b.y};
-                fold_rc<RULE, OPT>(st4, d, p.base + i0, p.m_s, next_arc, block_size, rstar, best);
+                if (CAND) fold_rc_best2(st4, d, p.base + i0, c1, p1, c2, p2);
+                else fold_rc<RULE, OPT>(st4, d, p.base + i0, p.m_s, next_arc, block_size, rstar, best);
             }
         }
-        publish_best<RULE, true, kResidentThreads>(best, p.slots + (size_t)blockIdx.x * kSlotStride, seq, true);
+        if (CAND) publish_candidates(c1, p1, c2, p2, p.slots, seq);
+        else publish_best<RULE, true, kResidentThreads>(best, p.slots + (size_t)blockIdx.x * kSlotStride, seq, true);
         last = seq;
         served += 1;
         idle_since = __builtin_amdgcn_s_memrealtime();

@@ -92,6 +92,13 @@ template <int RULE, bool OPT>
 void launch_resident_rc_r(mcf_engine *e, const ResidentRcParams &p)
 {
     const dim3 grid(e->res_grid), block(e->res_threads);
+    if constexpr (RULE == MCF_RULE_BEST_ELIGIBLE) {
+        if (e->cand_on) {          // the candidate cache's grid: every search publishes each group's smallest few, not only the best
+            if (e->rc_lds) hipExtLaunchKernelGGL((resident_rc_kernel<RULE, OPT, true, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+            else hipExtLaunchKernelGGL((resident_rc_kernel<RULE, OPT, false, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+            return;
+        }
+    }
     if (e->rc_lds) hipExtLaunchKernelGGL((resident_rc_kernel<RULE, OPT, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
     else hipExtLaunchKernelGGL((resident_rc_kernel<RULE, OPT, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
 }

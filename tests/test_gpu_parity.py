@@ -38,7 +38,9 @@ MODES = [pytest.param(M.ENGINE_NO_CANDIDATES, id="resident"), pytest.param(M.ENG
          pytest.param(M.ENGINE_SHARE_DEVICE, id="candidates-shared"),
          # reduced costs kept per arc (what large sparse instances use), forced onto these sizes: one dispatch per search, the resident grid
          # with the arcs in LDS, and the resident grid streaming them from memory
-         pytest.param("rc", id="rc-layout"), pytest.param("rc-resident", id="rc-resident-lds"), pytest.param("rc-stream", id="rc-resident-stream")]
+         pytest.param("rc", id="rc-layout"), pytest.param("rc-resident", id="rc-resident-lds"), pytest.param("rc-stream", id="rc-resident-stream"),
+         # ... and the candidate cache on top of either resident RC grid (Best Eligible on sparse graphs; the other rules run as above)
+         pytest.param("rc-cand", id="rc-candidates-lds"), pytest.param("rc-cand-stream", id="rc-candidates-stream")]
 CAND_MODES = (0, M.ENGINE_SHARE_DEVICE)
 
 
@@ -46,9 +48,9 @@ def _mode_flags(mode, monkeypatch):
     """Engine flags of a MODES entry; the "rc*" entries force the RC layout (MCF_HIP_RC=1) onto any size."""
     if isinstance(mode, str):
         monkeypatch.setenv("MCF_HIP_RC", "1")
-        if mode == "rc-stream":
+        if mode in ("rc-stream", "rc-cand-stream"):
             monkeypatch.setenv("MCF_HIP_RC_LDS", "0")
-        return M.ENGINE_DISPATCH if mode == "rc" else 0
+        return M.ENGINE_DISPATCH if mode == "rc" else (0 if mode.startswith("rc-cand") else M.ENGINE_NO_CANDIDATES)
     return mode
 
 
@@ -104,7 +106,9 @@ def test_scan_matches_oracle_on_random_arrays(width, rule, optimized, mode, monk
         if mode not in CAND_MODES:
             assert st["candidates"] == 0
         if rc_resident:
-            assert st["rc_layout"] == 1 and st["resident"] == 1 and st["resident_requests"] >= 12 and st["scan_bytes_read"] == 9 * m_s
+            assert st["rc_layout"] == 1 and st["resident"] == 1 and st["resident_requests"] + st["host_decided"] >= 12 and st["scan_bytes_read"] == 9 * m_s
+            assert st["candidates"] == int(mode == 0 and rule == O.RULE_BEST and 2 * m_s <= 24 * n)
+            assert st["candidates"] or st["resident_requests"] >= 12
         elif rc_layout:
             assert st["rc_layout"] == 1 and (st["update_launches"] > 0 or n < 100) and st["inline_updates"] > 0 and st["scan_bytes_read"] == 9 * m_s
         elif mode == M.ENGINE_DISPATCH:
@@ -663,7 +667,9 @@ def test_search_in_two_halves(mode, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [pytest.param(M.ENGINE_NO_CANDIDATES, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"),
                                   pytest.param(M.ENGINE_SHARE_DEVICE | M.ENGINE_NO_CANDIDATES, id="resident-shared"), pytest.param(0, id="candidates"),
-                                  pytest.param("rc", id="rc-layout"), pytest.param("rc-resident", id="rc-resident-lds"), pytest.param("rc-stream", id="rc-resident-stream")])
+                                  pytest.param("rc", id="rc-layout"), pytest.param("rc-resident", id="rc-resident-lds"), pytest.param("rc-stream", id="rc-resident-stream"),
+         # ... and the candidate cache on top of either resident RC grid (Best Eligible on sparse graphs; the other rules run as above)
+         pytest.param("rc-cand", id="rc-candidates-lds"), pytest.param("rc-cand-stream", id="rc-candidates-stream")])
 @pytest.mark.parametrize("m_s,n", [(400003, 100001), (60001, 16000)])
 def test_state_patch_lists_of_any_length(mode, m_s, n, monkeypatch):
     """mcf_engine_patch_state with 65, 200 and 5000 distinct arcs between two searches, each time with a potential list pending
@@ -871,7 +877,9 @@ def test_config5_solves_end_to_end_and_shards_follow_the_same_pivots():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [pytest.param(M.ENGINE_NO_CANDIDATES, id="resident"), pytest.param(M.ENGINE_DISPATCH, id="dispatch"), pytest.param(0, id="candidates-or-default"),
-                                  pytest.param("rc", id="rc-layout"), pytest.param("rc-resident", id="rc-resident-lds"), pytest.param("rc-stream", id="rc-resident-stream")])
+                                  pytest.param("rc", id="rc-layout"), pytest.param("rc-resident", id="rc-resident-lds"), pytest.param("rc-stream", id="rc-resident-stream"),
+         # ... and the candidate cache on top of either resident RC grid (Best Eligible on sparse graphs; the other rules run as above)
+         pytest.param("rc-cand", id="rc-candidates-lds"), pytest.param("rc-cand-stream", id="rc-candidates-stream")])
 def test_patch_arcs_rewrites_end_points_and_costs(mode, monkeypatch):
     """mcf_engine_patch_arcs (artificial arcs re-pointed by a warm start): source / target / cost of some arcs change between two searches;
     in the RC layout the per-arc reduced costs and the nodes' arc lists are rebuilt, and so are the candidate cache's host mirrors."""
@@ -946,7 +954,8 @@ def test_candidate_cache_survives_the_wrap_of_its_epoch_counter(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [pytest.param("rc", id="rc-layout"), pytest.param("rc-resident", id="rc-resident-lds"), pytest.param("rc-stream", id="rc-resident-stream")])
+@pytest.mark.parametrize("mode", [pytest.param("rc", id="rc-layout"), pytest.param("rc-resident", id="rc-resident-lds"), pytest.param("rc-stream", id="rc-resident-stream"),
+                                  pytest.param("rc-cand", id="rc-candidates-lds"), pytest.param("rc-cand-stream", id="rc-candidates-stream")])
 def test_rc_layout_with_hub_nodes(mode, monkeypatch):
     """RC layout on a graph with hubs (two nodes carry a third of the arc ends): a hub's arc list is far longer than what rides in a scan's
     arguments, and in update_rc_kernel it is walked by a whole workgroup instead of one thread."""
