@@ -269,9 +269,23 @@ def large_instance_sample(M, local_rank, with_cpu, gpu_pivots=3000, cpu_seconds=
            "us_per_pivot": m["loop_us"] / it, "pivot_search_us": m["pivot_search_us"] / it, "pivots_per_s": it / (m["loop_us"] / 1e6),
            "engine_mode": "resident grid" if m["engine"]["resident"] else "one dispatch per search",
            "layout": "reduced costs kept per arc (RC)" if m["engine"]["rc_layout"] else "SoA arcs + potential gathers",
-           "search_arcs": m["search_arc_num"], "bytes_read_per_scan": m["engine"]["scan_bytes_read"],
-           "scan_GBps_incl_round_trip": m["engine"]["scan_bytes_read"] / (m["pivot_search_us"] / it) / 1e3}
+           "candidate_cache": bool(m["engine"]["candidates"]), "searches_answered_on_the_host": m["engine"]["host_decided"],
+           "device_searches": m["engine"]["resident_requests"] if m["engine"]["resident"] else m["engine"]["scan_launches"],
+           "search_arcs": m["search_arc_num"], "bytes_read_per_scan": m["engine"]["scan_bytes_read"]}
     del ns
+    # the same pivots with every search on the device (what the whole solve's late phase does too: big subtrees leave the cache nothing to decide)
+    os.environ["MCF_HIP_CANDIDATES"] = "0"
+    try:
+        nsd = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True)
+        nsd.set_device(local_rank, 64, 0, 0).set_pivot_limit(gpu_pivots).record_trace(gpu_pivots).prepare()
+        nsd.solve()
+    finally:
+        os.environ.pop("MCF_HIP_CANDIDATES", None)
+    md = nsd.get_metrics(); itd = max(md["iterations"], 1)
+    out["every_search_on_the_device"] = {"pivots": md["iterations"], "us_per_pivot": md["loop_us"] / itd, "pivot_search_us": md["pivot_search_us"] / itd,
+                                         "scan_GBps_incl_round_trip": md["engine"]["scan_bytes_read"] / (md["pivot_search_us"] / itd) / 1e3,
+                                         "identical_pivot_sequence": bool((nsd.trace() == gpu_trace).all())}
+    del nsd
     # the same pivots with the arcs as 8 shards driven by ONE host thread, all eight engines on this one GPU (a rehearsal of mcf_ns_set_shard_group:
     # eight dispatches share the device, so this is the host-side cost of the sharded path plus 8 x a ninth of the scan, not a scaling figure)
     try:
@@ -422,6 +436,10 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+    # stdout carries the ONE JSON line and nothing else: whatever a library prints there (RCCL's version banner on some boxes) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -654,7 +672,8 @@ def main():
         line["large_instance_sample"] = large_instance_sample(M, local_rank, not args.no_cpu_baseline)
     if not args.no_validator and args.gpus == 1:
         line["solution_validator"] = validator_bench(M, g, solvers[0], local_rank, not args.no_cpu_baseline)
-    print(json.dumps(line), flush=True)
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
     if abandon:
         os._exit(0)
     if dist is not None:
