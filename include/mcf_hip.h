@@ -105,8 +105,8 @@ typedef struct mcf_engine_desc {
 #define MCF_ENGINE_NO_INLINE_UPDATE 4     /* always apply patches with the separate update kernel */
 #define MCF_ENGINE_RESIDENT 8             /* (default behaviour, kept for explicitness) serve searches from ONE resident scan grid fed
                                              through a mailbox in BAR-mapped VRAM instead of one dispatch per search */
-#define MCF_ENGINE_CANDIDATES 32          /* (default behaviour, kept for explicitness) Best Eligible, resident mode, register-resident arcs, sparse graph
-                                             (2 m_s <= 24 n): every device search also returns a candidate list that is complete below a threshold;
+#define MCF_ENGINE_CANDIDATES 32          /* (default behaviour, kept for explicitness) Best Eligible, resident mode (register-resident arcs, or the grid of the
+                                             per-arc reduced-cost layout that large instances get), sparse graph (2 m_s <= 24 n): every device search also returns a candidate list that is complete below a threshold;
                                              the following searches are answered on the host from that list plus a heap of the arcs the pivots
                                              touched, whenever that provably is the scan's answer, and the list is refreshed ahead of need
                                              (identical pivot sequence, a device round trip for about one search in seven).  DESIGN.md 3.4 */
