@@ -62,6 +62,9 @@ struct mcf_ns {
     std::vector<int32_t> moved;       // capacity n+1, the first moved_n entries are valid
     std::vector<int64_t> moved_val;   // their new potentials
     int moved_n = 0;
+    bool shift_smaller_side = false;  // inside mcf_ns_solve with 64-bit engines: see shift_potentials
+    bool allow_smaller_side = false;
+    int64_t dbg_hist_n[32] = {0}, dbg_hist_nodes[32] = {0}, dbg_over_half = 0, dbg_over_half_nodes = 0;   // MCF_NS_DEBUG: subtree sizes by log2
     int moved_sent = 0;               // how many of them the engine already has (handed over during the walk)
     int engine_rc = 0;                // first error of an engine call made from inside a pivot
     double piece_ticks = 0;           // time inside the hand-over calls made during the walks (part of the potential-update bucket)
@@ -384,8 +387,19 @@ void shift_potentials(mcf_ns *s)
     // runs BEFORE the re-hanging: the nodes that move are the subtree of u_out as it hangs now, and u_in's new parent direction is known
     const int8_t dir_in = s->u_in == s->tail[s->in_arc] ? kUp : kDown;
     s->sigma = s->pi[s->v_in] - s->pi[s->u_in] - dir_in * s->cost[s->in_arc];
+    int count = s->sub[s->u_out];
+    int first = s->u_out, last = s->fin[s->u_out];
+    if (s->shift_smaller_side && 2 * (int64_t)count > (int64_t)s->n + 1) {
+        // Reduced costs only see differences of potentials: moving the subtree by sigma and moving EVERYTHING ELSE by -sigma give the same
+        // search results.  Inside mcf_ns_solve the smaller side is walked -- the rest of the preorder list, from the node after the
+        // subtree's last one round to the node before u_out, the root included -- and the common offset (it is pi[root], which the
+        // reference keeps at 0) is taken out again before the solve returns (normalise_potentials).
+        s->sigma = -s->sigma;
+        first = s->nxt[last];
+        last = s->prv[s->u_out];
+        count = s->n + 1 - count;
+    }
     const int64_t sigma = s->sigma;
-    const int count = s->sub[s->u_out];
     s->moved_n = count;
     int32_t *const nodes = s->moved.data();
     int64_t *const vals = s->moved_val.data();
@@ -393,7 +407,7 @@ void shift_potentials(mcf_ns *s)
     const int32_t *const nxt = s->nxt.data(), *const prv = s->prv.data();
     if (count < kWalkHintMin) {
         int lo = 0, hi = count - 1;
-        int a = s->u_out, b = s->fin[s->u_out];
+        int a = first, b = last;
         while (lo < hi) {
             nodes[lo] = a; vals[lo] = (pi[a] += sigma); a = nxt[a]; ++lo;
             nodes[hi] = b; vals[hi] = (pi[b] += sigma); b = prv[b]; --hi;
@@ -402,7 +416,7 @@ void shift_potentials(mcf_ns *s)
         return;
     }
     int32_t *const follow = s->follow.data();
-    int a = s->u_out;
+    int a = first;
     const int piece = walk_piece();
     for (int i = 0; i < count; ++i) {
         const int h = follow[a];
@@ -421,6 +435,21 @@ void shift_potentials(mcf_ns *s)
             s->moved_sent = i + 1;
         }
     }
+}
+
+// pi[root] back to 0 (where the reference keeps it): every potential moves by -pi[root], the engines hear of it as one list of all nodes
+int normalise_potentials(mcf_ns *s)
+{
+    const int64_t off = s->pi[s->root];
+    if (off == 0) return MCF_OK;
+    const int total = s->n + 1;
+    for (int u = 0; u < total; ++u) { s->moved[u] = u; s->moved_val[u] = (s->pi[u] -= off); }
+    s->sigma = -off;
+    s->moved_n = total;
+    s->moved_sent = 0;
+    const int rc = engines_append_potential(s, total, s->moved.data(), s->moved_val.data());
+    s->moved_sent = total;
+    return rc;
 }
 
 // One pivot with a given entering arc, in two halves.  pivot_front does what the next search depends on -- the cycle, the State[] writes and
@@ -737,6 +766,8 @@ int mcf_ns_prepare(mcf_ns *s)
     d.arc_capacity = (int32_t)s->tail.size();
     d.search_arc_num = s->search_arcs;
     d.int_width = pick_int_width(s);
+    // 32-bit engines check that every potential fits: the common offset of shift_potentials' smaller-side walk could break that, so they walk the subtree
+    s->allow_smaller_side = d.int_width == 64 && !(getenv("MCF_NS_SMALLER_SIDE") && getenv("MCF_NS_SMALLER_SIDE")[0] == '0');
     d.rule = s->rule;
     d.semantics = s->optimized_pivot ? MCF_SEM_OPTIMIZED : MCF_SEM_PLAIN;
     d.block_size = s->block_size;
@@ -812,6 +843,7 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     s->hand_over = true;
     s->engine_rc = 0;
     s->piece_ticks = 0;
+    s->shift_smaller_side = s->allow_smaller_side;
     // The search for pivot k+1 is posted as soon as the device has what it depends on (State[] writes, potentials); the rest of pivot k
     // (flows around the cycle, re-hanging the subtree) runs while the device is searching.  Engines sharded over RCCL search in one
     // blocking call (the all-gather runs on their stream), so for them the two halves simply follow each other.
@@ -840,9 +872,13 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         if (rc) break;                     // the pivot stays half done: the solver is unusable after an engine error, but nothing is left running
         pivot_back(s, &t_tree);
         s->metrics.potential_nodes += (int64_t)s->moved_n;
+        { const int b = 31 - __builtin_clz((unsigned)std::max(s->moved_n, 1)); s->dbg_hist_n[b] += 1; s->dbg_hist_nodes[b] += s->moved_n;
+          if (2 * (int64_t)s->moved_n > s->n) { s->dbg_over_half += 1; s->dbg_over_half_nodes += s->moved_n; } }
     }
     // ONE way out, error or not: no hand-over pending, no resident grid left spinning, trace length and iteration count filled in
     s->hand_over = false;
+    s->shift_smaller_side = false;
+    if (!rc) rc = normalise_potentials(s);
     const char *first_error = rc ? mcf_last_error() : nullptr;
     std::string keep_error = first_error ? first_error : "";
     engines_park(s);                 // a resident scan grid must not outlive Solve()
@@ -858,6 +894,11 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         fprintf(stderr, "[ns] per pivot ns: search wait %.0f | walk %.0f | pieces handed over during walks %.0f | last hand-over %.0f | search begin %.0f | tree %.0f | everything else %.0f\n",
                 t_search * ns_per_tick / it, (t_pot - t_hand - t_begin - s->piece_ticks) * ns_per_tick / it, s->piece_ticks * ns_per_tick / it, t_hand * ns_per_tick / it, t_begin * ns_per_tick / it, t_tree * ns_per_tick / it,
                 ((ticks() - tick_start) - t_search - t_pot - t_tree) * ns_per_tick / it);
+    if (getenv("MCF_NS_DEBUG") && it > 1000) {
+        fprintf(stderr, "[ns] moved subtrees by size (pivots / nodes):");
+        for (int b = 0; b < 32; ++b) if (s->dbg_hist_n[b]) fprintf(stderr, " 2^%d: %lld / %lld |", b, (long long)s->dbg_hist_n[b], (long long)s->dbg_hist_nodes[b]);
+        fprintf(stderr, " more than half of the %d nodes: %lld / %lld\n", s->n, (long long)s->dbg_over_half, (long long)s->dbg_over_half_nodes);
+    }
     mcf_engine_get_stats(s->engine, &s->metrics.engine);
     // the rest of SolverMetrics: NS.cs:262-270 (initial block size), :276 (expected iterations), :344-357
     const bool plain_block = s->rule == MCF_RULE_BLOCK_SEARCH && !s->optimized_pivot;
