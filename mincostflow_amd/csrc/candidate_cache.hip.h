@@ -76,7 +76,7 @@ inline void cand_push(mcf_engine *e, int a)
     const int64_t d = e->h_cost[a] + pi[e->h_src[a]] - pi[e->h_tgt[a]];
     const int64_t rc = st > 0 ? d : -d;
     if (rc >= 0) return;
-    e->heap.push_back(mcf_engine::HeapEnt{rc, (uint32_t)a, stamp});
+    e->heap.push_back(mcf_engine::HeapEnt{rc, (uint32_t)a, stamp, e->cand_now});
     std::push_heap(e->heap.begin(), e->heap.end(), CandHeapAfter());
 }
 
@@ -89,6 +89,14 @@ void cand_absorb_pivot(mcf_engine *e)
         // (entries are only trusted for snapshots taken at or after heap_gap, and those know the arcs' present keys -- see cand_decide)
     } else {
         const int64_t *pi = cand_pi(e);
+        const uint32_t now = e->cand_now;
+        // first the addresses the evaluation will miss on (version counters and far potentials live in arrays of the graph's size) ...
+        for (int u : e->pivot_nodes)
+            for (int i = e->adj_start[u], hi = e->adj_start[u + 1]; i < hi; ++i) {
+                const mcf_engine::AdjEnt &x = e->adj[i];
+                __builtin_prefetch(&e->arc_stamp[x.arc], 1);
+                __builtin_prefetch(&pi[x.other & 0x1FFFFFFFu]);
+            }
         for (int u : e->pivot_nodes) {
             const int64_t pu = pi[u];
             // everything an evaluation needs sits in the entry except the other end's potential and the arc's version counter; an arc
@@ -102,7 +110,7 @@ void cand_absorb_pivot(mcf_engine *e)
                 const int64_t d = (x.other >> 31) ? x.cost + po - pu : x.cost + pu - po;
                 const int64_t rc = st > 0 ? d : -d;
                 if (rc >= 0) continue;
-                e->heap.push_back(mcf_engine::HeapEnt{rc, (uint32_t)x.arc, stamp});
+                e->heap.push_back(mcf_engine::HeapEnt{rc, (uint32_t)x.arc, stamp, now});
                 std::push_heap(e->heap.begin(), e->heap.end(), CandHeapAfter());
             }
         }
@@ -133,16 +141,25 @@ bool cand_decide(mcf_engine *e, Key *k)
     while (!e->heap.empty()) {
         const mcf_engine::HeapEnt &t = e->heap.front();
         const uint32_t a = t.p;
-        // current version, and touched after the snapshot (an arc last touched before it is the list's business)
+        // current version, and touched after the snapshot (an arc last touched before it is the list's business).  While an entry is
+        // current its own epoch is the arc's last touch: a later touch either pushed a newer entry or was a skipped one, i.e. a gap -- and
+        // no list older than a gap gets here (above), so both the entry's epoch and the true one are <= snap_at then.
         const bool fresh = t.stamp == e->arc_stamp[a];
-        const bool after = e->arc_at[a] > e->snap_at || e->node_at[e->h_src[a]] > e->snap_at || e->node_at[e->h_tgt[a]] > e->snap_at;
+        const bool after = t.at > e->snap_at;
         if (fresh && after) { best_d = mcf_engine::CandKey{t.c, a}; break; }
         std::pop_heap(e->heap.begin(), e->heap.end(), CandHeapAfter());
         e->heap.pop_back();
     }
     while (e->cand_ptr < e->cand_list.size()) {
         const uint32_t a = e->cand_list[e->cand_ptr].p;
-        if (e->arc_at[a] <= e->snap_at && e->node_at[e->cand_ends[2 * e->cand_ptr]] <= e->snap_at && e->node_at[e->cand_ends[2 * e->cand_ptr + 1]] <= e->snap_at) break;
+        // three independent loads (no short circuit: they miss together), and the next entry's lines are asked for meanwhile
+        if (e->cand_ptr + 1 < e->cand_list.size()) {
+            __builtin_prefetch(&e->arc_at[e->cand_list[e->cand_ptr + 1].p]);
+            __builtin_prefetch(&e->node_at[e->cand_ends[2 * e->cand_ptr + 2]]);
+            __builtin_prefetch(&e->node_at[e->cand_ends[2 * e->cand_ptr + 3]]);
+        }
+        const uint32_t t_arc = e->arc_at[a], t_src = e->node_at[e->cand_ends[2 * e->cand_ptr]], t_tgt = e->node_at[e->cand_ends[2 * e->cand_ptr + 1]];
+        if ((t_arc <= e->snap_at) & (t_src <= e->snap_at) & (t_tgt <= e->snap_at)) break;
         e->cand_ptr++;
     }
     mcf_engine::CandKey win{0, kNone};

@@ -182,7 +182,7 @@ struct mcf_engine {
     uint32_t snap_at = 0;                         // epoch the candidate list reflects
     uint32_t heap_gap = 0;                        // latest epoch whose changes were NOT evaluated into the heap (a subtree too big to evaluate here)
     struct CandKey { int64_t c; uint32_t p; };
-    struct HeapEnt { int64_t c; uint32_t p; uint32_t stamp; };
+    struct HeapEnt { int64_t c; uint32_t p; uint32_t stamp; uint32_t at; };      // at: the epoch of the touch that pushed it (= the arc's last touch while the entry is current)
     std::vector<HeapEnt> heap;                    // min-heap of the current keys of the arcs touched since (lazy deletion through arc_stamp)
     std::vector<int32_t> pivot_nodes, pivot_arcs; // touched since the last search: evaluated when the next search begins (all values final by then)
     int64_t pivot_degree = 0;
