@@ -265,6 +265,8 @@ typedef struct mcf_engine_stats {
     int64_t scan_bytes_read;      /* bytes one scan of THIS engine's layout has to read: bytes_per_scan for the gathering layouts, 9 per arc
                                      (state + the arc's reduced cost) in the RC layout, where the gathers moved into the potential update */
     int64_t rc_layout;            /* 1: reduced costs are kept per arc (large sparse instances) */
+    int64_t rc_recomputes;        /* RC layout: potential lists naming more than a sixteenth of the nodes, after which every reduced cost of the
+                                     shard was computed again instead of shifting the listed nodes' arcs one by one */
 } mcf_engine_stats;
 MCF_API int mcf_engine_get_stats(mcf_engine *e, mcf_engine_stats *out);
 MCF_API int mcf_engine_reset_stats(mcf_engine *e);

@@ -118,6 +118,7 @@ struct mcf_engine {
     int32_t *d_adj_start = nullptr;
     uint32_t *d_adj = nullptr;     // the shard's arcs at each node: local position, bit 31 = the node is the arc's target
     std::vector<int32_t> h_adj_start;   // host copy of d_adj_start (short lists name their arc lists in the scan's arguments)
+    int rc_recompute_above = INT32_MAX;   // RC layout: potential lists longer than this are followed by a full recomputation instead of per-arc shifts
     bool pend_shift = false;       // every pending potential is its node's previous value + pend_sigma (mcf_engine_shift_potential)
     int64_t pend_sigma = 0;
     bool no_pireg = false;         // MCF_ENGINE_SHARE_DEVICE or MCF_HIP_PIREG=0: the resident grid gathers the potentials for every request
@@ -474,7 +475,20 @@ int flush_pending(mcf_engine *e)
         if (n_pi) { memcpy(s.nodes, e->pend_node.data(), sizeof(int32_t) * n_pi); memcpy(s.values, e->pend_val.data(), sizeof(int64_t) * n_pi); }
         if (n_st) { memcpy(s.arcs, e->pend_arc.data() + st0, sizeof(int32_t) * n_st); memcpy(s.states, e->pend_state.data() + st0, sizeof(int32_t) * n_st); }
         const int blocks = (std::max(n_pi, n_st) + kThreads - 1) / kThreads;
-        if (e->rc_mode && e->d.int_width == 32)
+        // RC layout, a list that names more than a sixteenth of the nodes: shifting their arcs one by one (2 ns per node on config 5: 18 atomics in
+        // memory each) costs more than writing the potentials and computing every reduced cost of the shard again (12 ps per arc: 107 us for 9 M arcs)
+        const bool recompute = e->rc_mode && n_pi > e->rc_recompute_above;
+        if (recompute) {
+            if (e->d.int_width == 32)
+                hipLaunchKernelGGL(update_kernel<int32_t>, dim3(blocks), dim3(kThreads), 0, e->stream, (int32_t *)e->d_pi, (const int32_t *)s.d_nodes,
+                                   (const int64_t *)s.d_values, n_pi, e->d_state, (const int32_t *)s.d_arcs, (const int32_t *)s.d_states, n_st, e->begin, e->count_padded);
+            else
+                hipLaunchKernelGGL(update_kernel<int64_t>, dim3(blocks), dim3(kThreads), 0, e->stream, (int64_t *)e->d_pi, (const int32_t *)s.d_nodes,
+                                   (const int64_t *)s.d_values, n_pi, e->d_state, (const int32_t *)s.d_arcs, (const int32_t *)s.d_states, n_st, e->begin, e->count_padded);
+            HIP_TRY(hipGetLastError());
+            if (int rcr = rc_recompute(e)) return rcr;
+            e->st.rc_recomputes += 1;
+        } else if (e->rc_mode && e->d.int_width == 32)
             hipLaunchKernelGGL(update_rc_kernel<int32_t>, dim3(blocks), dim3(kThreads), 0, e->stream, (int32_t *)e->d_pi, (const int32_t *)s.d_nodes, (const int64_t *)s.d_values, n_pi,
                                e->d_state, (const int32_t *)s.d_arcs, (const int32_t *)s.d_states, n_st, e->begin, e->count_padded, e->d_rc, e->d_adj_start, e->d_adj);
         else if (e->rc_mode)
@@ -827,6 +841,8 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
             // measured on config 5's arrays (profiles/r02_rc_layout_scan.txt, r02_rc_layout_scan_threads.txt): everything between 256 and 1024
             // workgroups of 256 .. 1024 threads lands within 14.3-15.6 us warm / 16.6-17.7 cold for 81 MB; 512 x 256 with two tiles per trip is
             // the best of them, more workgroups only add launch ramp and tail
+            e->rc_recompute_above = std::max(1024, desc->node_count / 16);
+            if (const char *u = getenv("MCF_HIP_RC_RECOMPUTE")) { const long long v = atoll(u); e->rc_recompute_above = v <= 0 || v > INT32_MAX ? INT32_MAX : (int)v; }    // 0: never
             e->unroll = count > (1 << 20) ? 2 : 1;
             if (const char *u = getenv("MCF_HIP_UNROLL")) { const int v = atoi(u); if (v == 1 || v == 2 || v == 4) e->unroll = v; }
             if (const char *u = getenv("MCF_HIP_RC_THREADS")) { const int v = atoi(u); if (v == 256 || v == 512 || v == 1024) e->rc_threads = v; }
