@@ -117,7 +117,7 @@ struct mcf_engine {
     int64_t *d_rc = nullptr;
     int32_t *d_adj_start = nullptr;
     uint32_t *d_adj = nullptr;     // the shard's arcs at each node: local position, bit 31 = the node is the arc's target
-    std::vector<int32_t> h_adj_start;   // host copy of d_adj_start (short lists name their arc lists in the scan's arguments)
+    mcf::hvec<int32_t> h_adj_start;   // host copy of d_adj_start (short lists name their arc lists in the scan's arguments)
     int rc_recompute_above = INT32_MAX;   // RC layout: potential lists longer than this are followed by a full recomputation instead of per-arc shifts
     bool pend_shift = false;       // every pending potential is its node's previous value + pend_sigma (mcf_engine_shift_potential)
     int64_t pend_sigma = 0;
@@ -126,13 +126,13 @@ struct mcf_engine {
     uint32_t seq = 0;
     bool uploaded = false;
     // host mirror of pi: patches carry final values
-    std::vector<int64_t> pi;
+    mcf::hvec<int64_t> pi;
     bool mirror_valid = false;     // mcf_engine_set_potential stops maintaining the mirror; update_potential rebuilds it on demand
     const int64_t *ext_pi = nullptr;   // mcf_engine_bind_potentials: the caller's own array is read instead of the mirror (no second copy to keep up to date)
     int64_t max_abs_cost = 0;
     // pending patches of the current pivot
-    std::vector<int32_t> pend_node, pend_arc, pend_state;
-    std::vector<int64_t> pend_val;
+    mcf::hvec<int32_t> pend_node, pend_arc, pend_state;
+    mcf::hvec<int64_t> pend_val;
     // staging for lists that do not fit the kernel arguments (pinned, read by update_kernel over PCIe)
     struct Staging {
         int32_t *nodes = nullptr, *arcs = nullptr, *states = nullptr;
@@ -169,16 +169,16 @@ struct mcf_engine {
     uint32_t prev_seq = 0;
     // candidate cache (Best Eligible, resident, register-resident tiles, sparse graphs): see cand_* below
     bool cand_on = false, cand_valid = false;
-    std::vector<int32_t> h_src, h_tgt;            // host mirrors of the resident arrays (search arcs only)
-    std::vector<int64_t> h_cost;
-    std::vector<int8_t> h_state;
+    mcf::hvec<int32_t> h_src, h_tgt;            // host mirrors of the resident arrays (search arcs only)
+    mcf::hvec<int64_t> h_cost;
+    mcf::hvec<int8_t> h_state;
     struct AdjEnt { int32_t arc; uint32_t other; int64_t cost; };  // other: the arc's second end point (bits 0-28), the arc's state + 1 (bits 29-30), bit 31 set when THIS node is the arc's target
-    std::vector<int32_t> adj_start;
-    std::vector<AdjEnt> adj;                      // arcs incident to each node, with what a re-evaluation needs next to each other
+    mcf::hvec<int32_t> adj_start;
+    mcf::hvec<AdjEnt> adj;                      // arcs incident to each node, with what a re-evaluation needs next to each other
     // every change carries the number of the search it precedes ("epoch"); a snapshot taken at epoch P knows all changes stamped <= P
-    std::vector<uint32_t> node_at, arc_at;        // epoch of the node's last potential change / the arc's last state change
-    std::vector<uint32_t> arc_stamp;              // version of the arc's key; heap entries of an older version are stale
-    std::vector<int32_t> adj_pos;                 // where the two entries of an arc sit in adj (the second is -1 for a self loop): a state write reaches both
+    mcf::hvec<uint32_t> node_at, arc_at;        // epoch of the node's last potential change / the arc's last state change
+    mcf::hvec<uint32_t> arc_stamp;              // version of the arc's key; heap entries of an older version are stale
+    mcf::hvec<int32_t> adj_pos;                 // where the two entries of an arc sit in adj (the second is -1 for a self loop): a state write reaches both
     uint32_t cand_now = 1;                        // epoch of the changes that are arriving
     uint32_t snap_at = 0;                         // epoch the candidate list reflects
     uint32_t heap_gap = 0;                        // latest epoch whose changes were NOT evaluated into the heap (a subtree too big to evaluate here)
@@ -452,7 +452,7 @@ int rc_build_adjacency(mcf_engine *e, const int32_t *src_local, const int32_t *t
         adj[fill[tgt_local[i]]++] = (uint32_t)i | 0x80000000u;
     }
     HIP_TRY(hipMemcpy(e->d_adj_start, start.data(), sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
-    e->h_adj_start = start;
+    e->h_adj_start.assign(start.begin(), start.end());
     HIP_TRY(hipMemcpy(e->d_adj, adj.data(), sizeof(uint32_t) * adj.size(), hipMemcpyHostToDevice));
     return MCF_OK;
 }

@@ -37,13 +37,13 @@ struct mcf_ns {
     bool auto_config = true;                                           // NS.cs:90
     mcf_block_config config{};                                         // _optimizationConfig, NS.cs:89
     // arcs: m + 2n entries (NS.cs:130)
-    std::vector<int32_t> tail, head;
-    std::vector<int64_t> lower, upper, cost, flow, orig_lower;
-    std::vector<int8_t> state;
+    mcf::hvec<int32_t> tail, head;
+    mcf::hvec<int64_t> lower, upper, cost, flow, orig_lower;
+    mcf::hvec<int8_t> state;
     // nodes: n + 1 entries, the last one is the artificial root (NS.cs:137,144)
-    std::vector<int64_t> supply, pi;
-    std::vector<int32_t> par, par_arc, nxt, prv, sub, fin;   // Parent, Pred, Thread, RevThread, SuccNum, LastSucc
-    std::vector<int8_t> par_dir;
+    mcf::hvec<int64_t> supply, pi;
+    mcf::hvec<int32_t> par, par_arc, nxt, prv, sub, fin;   // Parent, Pred, Thread, RevThread, SuccNum, LastSucc
+    mcf::hvec<int8_t> par_dir;
     std::vector<int32_t> scratch;
     int64_t sum_supply = 0, art_cost = 0;
     int status = MCF_NOT_SOLVED;
@@ -58,9 +58,9 @@ struct mcf_ns {
     int n_state = 0;
     int32_t st_arc[2] = {0, 0};
     int8_t st_val[2] = {0, 0};
-    std::vector<int32_t> follow;      // prefetch hints of shift_potentials
-    std::vector<int32_t> moved;       // capacity n+1, the first moved_n entries are valid
-    std::vector<int64_t> moved_val;   // their new potentials
+    mcf::hvec<int32_t> follow;      // prefetch hints of shift_potentials
+    mcf::hvec<int32_t> moved;       // capacity n+1, the first moved_n entries are valid
+    mcf::hvec<int64_t> moved_val;   // their new potentials
     int moved_n = 0;
     bool shift_smaller_side = false;  // inside mcf_ns_solve with 64-bit engines: see shift_potentials
     bool allow_smaller_side = false;
