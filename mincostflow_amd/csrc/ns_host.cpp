@@ -418,21 +418,36 @@ void shift_potentials(mcf_ns *s)
     int32_t *const follow = s->follow.data();
     int a = first;
     const int piece = walk_piece();
-    for (int i = 0; i < count; ++i) {
+    // the first kWalkAhead nodes have no node that far behind them to leave a hint with (count >= kWalkHintMin > kWalkAhead)
+    int i = 0;
+    for (; i < kWalkAhead; ++i) {
         const int h = follow[a];
         __builtin_prefetch(&nxt[h]);
         __builtin_prefetch(&pi[h]);
         __builtin_prefetch(&follow[h]);
         nodes[i] = a;
         vals[i] = (pi[a] += sigma);
-        if (i >= kWalkAhead) follow[nodes[i - kWalkAhead]] = a;
         a = nxt[a];
-        if (s->hand_over && i + 1 - s->moved_sent >= piece && count - (i + 1) >= piece / 2) {
+    }
+    while (i < count) {
+        // up to the next point where a piece may be handed over (a piece's worth of nodes since the last one, at least half a piece still to come)
+        const int stop = s->hand_over && count - (s->moved_sent + piece) >= piece / 2 ? std::max(i, s->moved_sent + piece) : count;
+        for (; i < stop; ++i) {
+            const int h = follow[a];
+            __builtin_prefetch(&nxt[h]);
+            __builtin_prefetch(&pi[h]);
+            __builtin_prefetch(&follow[h]);
+            nodes[i] = a;
+            vals[i] = (pi[a] += sigma);
+            follow[nodes[i - kWalkAhead]] = a;
+            a = nxt[a];
+        }
+        if (i < count) {
             // the grid applies this piece while the walk goes on (resident mode); the search after the pivot finishes the list
             const double tp = ticks();
-            if (!s->engine_rc) s->engine_rc = engines_append_potential(s, i + 1 - s->moved_sent, nodes + s->moved_sent, vals + s->moved_sent);
+            if (!s->engine_rc) s->engine_rc = engines_append_potential(s, i - s->moved_sent, nodes + s->moved_sent, vals + s->moved_sent);
             s->piece_ticks += ticks() - tp;
-            s->moved_sent = i + 1;
+            s->moved_sent = i;
         }
     }
 }
