@@ -91,7 +91,8 @@ typedef struct mcf_engine_desc {
                                  (BSPO.cs:27-28 / NS.cs:1304-1336 with the default OptimizationConfig) */
     int32_t device;           /* HIP device ordinal */
     /* arc shard owned by this engine, [shard_begin, shard_end) within [0, search_arc_num); 0,0 = all.
-     * A sharded engine answers for its shard only (mcf_engine_find_entering_local). */
+     * A sharded engine answers for its shard only (mcf_engine_find_entering_local); its candidate cache (MCF_ENGINE_CANDIDATES) covers the
+     * shard's arcs, so a holder asks its device only when ITS range cannot be decided on the host. */
     int32_t shard_begin, shard_end;
     int32_t scan_workgroups;  /* 0 = auto; otherwise the grid of the scan kernel */
     int32_t flags;            /* MCF_ENGINE_* */

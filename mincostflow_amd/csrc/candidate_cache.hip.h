@@ -338,13 +338,16 @@ void cand_build_adjacency(mcf_engine *e)
 {
     const int n = e->d.node_count, m_s = e->d.search_arc_num;
     const int32_t *source = e->h_src.data(), *target = e->h_tgt.data();
+    // an arc shard keeps its own cache: the list, the heap and this adjacency cover the arcs [begin, end) it holds, the answer is the shard's
+    // candidate (mcf_engine_search_end_local) and the holders' MINLOC does the rest
+    const int lo = e->begin, hi = std::min(e->end, m_s);
     e->adj_start.assign(n + 1, 0);
-    for (int a = 0; a < m_s; ++a) { e->adj_start[source[a] + 1]++; if (target[a] != source[a]) e->adj_start[target[a] + 1]++; }
+    for (int a = lo; a < hi; ++a) { e->adj_start[source[a] + 1]++; if (target[a] != source[a]) e->adj_start[target[a] + 1]++; }
     for (int u = 0; u < n; ++u) e->adj_start[u + 1] += e->adj_start[u];
     e->adj.assign(e->adj_start[n], mcf_engine::AdjEnt{0, 0u, 0});
     e->adj_pos.assign((size_t)2 * m_s, -1);
     std::vector<int32_t> fill(e->adj_start.begin(), e->adj_start.end() - 1);
-    for (int a = 0; a < m_s; ++a) {
+    for (int a = lo; a < hi; ++a) {
         const uint32_t st_bits = (uint32_t)(e->h_state[a] + 1) << 29;
         e->adj_pos[2 * (size_t)a] = fill[source[a]];
         e->adj[fill[source[a]]++] = mcf_engine::AdjEnt{a, (uint32_t)target[a] | st_bits, e->h_cost[a]};

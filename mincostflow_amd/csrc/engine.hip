@@ -193,6 +193,7 @@ struct mcf_engine {
                                                   // first blind_count entries of pend_node / pend_val already (and may have started travelling)
     uint32_t blind_epoch = 0;                     // epoch of the first of those lists
     int blind_sets = 0;                           // lists in there that did not come as the continuation of another one
+    bool force_device_search = false;             // mcf_engine_bench_search: every search goes to the device (the cache would answer without one)
     bool cand_appending = false;                  // mcf_engine_append_potential is calling mcf_engine_set_potential
     struct NodeShift { int32_t node; int64_t shift; };
     std::vector<NodeShift> rc_sync;               // RC layout: the small lists' nodes with the shift of their pivot, one entry per occurrence
@@ -547,8 +548,9 @@ int search_begin(mcf_engine *e)
             if (e->async_posted && cand_records_ready(e, 0)) { int rc = cand_collect(e, e->async_at); if (rc) return rc; }      // the refresh has arrived
             const double tc = (double)__rdtsc();
             e->tk_probe += tc - tb;
-            bool decided = cand_decide(e, k);
+            bool decided = !e->force_device_search && cand_decide(e, k);
             e->tk_decide += (double)__rdtsc() - tc;
+            if (e->force_device_search && e->async_posted) { int rc = cand_collect(e, e->async_at); if (rc) return rc; }       // one request at a time
             if (!decided && e->async_posted) {              // the refresh is what we are waiting for
                 e->n_async_waits += 1;
                 int rc = cand_collect(e, e->async_at);
@@ -908,7 +910,6 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         if (env && env[0] == '0') want = false;
         // an arc shard is served by a resident grid like a whole instance (every workgroup applies every potential patch, state patches
         // outside the shard are ignored); only the RCCL exchange needs the stream, and mcf_engine_comm_init switches to dispatch mode
-        const bool whole = e->begin == 0 && e->end == desc->search_arc_num;
         if (want && !(desc->flags & (MCF_ENGINE_TIME_EVERY_KERNEL | MCF_ENGINE_NO_INLINE_UPDATE))) {
             e->mailbox_max_st = 4096;
             e->mailbox_lines = 2 + (e->patch_capacity + e->mailbox_max_st + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
@@ -934,7 +935,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
                     e->resident_reg = false;
                 }
                 e->cand_on = !(desc->flags & MCF_ENGINE_NO_CANDIDATES) && !(getenv("MCF_HIP_CANDIDATES") && getenv("MCF_HIP_CANDIDATES")[0] == '0') &&
-                             whole && (e->resident_reg || e->rc_mode) && desc->rule == MCF_RULE_BEST_ELIGIBLE && desc->node_count < (1 << 29) &&
+                             (e->resident_reg || e->rc_mode) && desc->rule == MCF_RULE_BEST_ELIGIBLE && desc->node_count < (1 << 29) &&
                              2 * (int64_t)desc->search_arc_num <= (int64_t)kCandMaxAvgDegree * desc->node_count;
             }
         }
@@ -1547,6 +1548,8 @@ int mcf_engine_bench_search(mcf_engine *e, int32_t reps, double *avg_ns, double 
     if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
     HIP_TRY(hipSetDevice(e->d.device));
     Key k;
+    struct Forced { mcf_engine *e; ~Forced() { e->force_device_search = false; } } forced{e};
+    e->force_device_search = true;
     for (int r = 0; r < 16; ++r) { const int rc = local_search(e, &k); if (rc) return rc; }      // the grid is up, the caches are warm
     double sum = 0, mn = 1e30;
     for (int r = 0; r < reps; ++r) {

@@ -558,7 +558,7 @@ def test_bucketed_layout_on_arc_shards(monkeypatch):
     a = _random_soa(rng, m_s, n, 2, 6, extra=0)
     shards = []
     for r in range(world):
-        e = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible, optimized=True, shard=M.shard_range(m_s, r, world))
+        e = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible, optimized=True, shard=M.shard_range(m_s, r, world), flags=M.ENGINE_NO_CANDIDATES)
         e.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
         shards.append(e)
     for it in range(10):
@@ -579,6 +579,54 @@ def test_bucketed_layout_on_arc_shards(monkeypatch):
         b, en = M.shard_range(m_s, shards.index(e), world)
         full[b:en] = st[b:en]
     assert np.array_equal(full, a["state"][:m_s])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["registers", "rc-lds", "rc-stream"])
+def test_arc_shards_keep_their_own_candidate_caches(layout, monkeypatch):
+    """Best Eligible on a sparse graph: every shard engine keeps a candidate cache over ITS arcs (list + heap + adjacency of [begin, end)),
+    answers mcf_engine_search_end_local from the host when it can and asks its own grid when it cannot; the holders' MINLOC of the shard
+    candidates is the oracle's entering arc after every kind of change (single nodes, lists of a pivot's size, lists too big to evaluate,
+    state writes inside and outside a shard)."""
+    if layout != "registers":
+        monkeypatch.setenv("MCF_HIP_RC", "1")
+        if layout == "rc-stream":
+            monkeypatch.setenv("MCF_HIP_RC_LDS", "0")
+    rng = np.random.default_rng(77)
+    m_s, n, world = 180_007, 40_000, 3
+    a = _random_soa(rng, m_s, n, 40, 300, extra=0)
+    shards = []
+    for r in range(world):
+        e = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible, optimized=True, shard=M.shard_range(m_s, r, world), resident_workgroups=64)
+        e.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+        assert e.stats()["candidates"] == 1 and e.stats()["resident"] == 1
+        shards.append(e)
+    for it in range(400):
+        f, arc, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+        for e in shards:
+            e.search_begin()
+        cands = [e.search_end_local() for e in shards]
+        got = [e.resolve(cands) for e in shards]
+        assert all(g[0] == f and (not f or (g[1], g[2]) == (arc, c)) for g in got), (it, got, arc, c)
+        if not f:
+            break
+        # a pivot-like change: the entering arc joins the basis, another arc leaves it, a subtree's potentials move by the entering arc's reduced cost
+        leave = int(rng.integers(0, m_s))
+        arcs = np.array([arc, leave], np.int32); vals = np.array([0, int(rng.choice([-1, 1]))], np.int8)
+        a["state"][arcs] = vals
+        k = int(rng.choice([1, 1, 1, 2, 5, 30, 90, 400, 5000]))
+        nodes = rng.choice(n, size=k, replace=False).astype(np.int32)
+        sigma = int(c) if it % 3 else -int(c)
+        a["pi"][nodes] += sigma
+        for e in shards:
+            e.patch_state(arcs, vals)
+            e.shift_potential(nodes, a["pi"][nodes], sigma)
+    st = [e.stats() for e in shards]
+    assert sum(x["host_decided"] for x in st) > 0 and all(x["host_decided"] + x["resident_requests"] >= it for x in st), st
+    for r, e in enumerate(shards):
+        assert np.array_equal(e.download_pi(), a["pi"])
+        b, en = M.shard_range(m_s, r, world)
+        assert np.array_equal(e.download_state()[b:en], a["state"][b:en])
 
 
 @pytest.mark.gpu
@@ -797,7 +845,8 @@ def test_resident_shard_engines_resolve_like_one_engine(rule, optimized):
                 e.patch_state(arcs, vals)
                 e.update_potential(nodes, -3)
     st = [e.stats() for e in shards]
-    assert all(x["resident_requests"] >= 12 for x in st)
+    assert all(x["resident_requests"] + x["host_decided"] >= 12 for x in st)          # Best Eligible: every shard answers from its own candidate cache when it can
+    assert all(x["candidates"] == (1 if rule == O.RULE_BEST else 0) for x in st)
 
 
 @pytest.mark.gpu
