@@ -162,7 +162,9 @@ def sharded_leg(M, torch, dist, args, rank, world, dev, barrier, red_dev):
     sec, m5, tr_host = run(lambda ns: ns.set_sharding_host(f"/mcf_bench_{port}_{os.getppid()}", rank, world))
     out["variants"]["host_exchange"] = {"exchange": "16-byte records through POSIX shared memory (mcf_exchange_all_gather), resident or dispatch scan per shard",
                                         "ranks": world, "pivots": m5["iterations"], "seconds": sec, "us_per_pivot": sec / max(m5["iterations"], 1) * 1e6,
-                                        "pivots_per_s": m5["iterations"] / sec, "shard_engine_resident": bool(m5["engine"]["resident"])}
+                                        "pivots_per_s": m5["iterations"] / sec, "shard_engine_resident": bool(m5["engine"]["resident"]),
+                                        "shard_candidate_cache": bool(m5["engine"]["candidates"]), "rank0_searches_answered_on_the_host": m5["engine"]["host_decided"],
+                                        "rank0_device_searches": m5["engine"]["resident_requests"] if m5["engine"]["resident"] else m5["engine"]["scan_launches"]}
     same = True
     # the same pivots on ONE GPU (rank 0 alone, un-sharded), the figure the sharded ones have to beat
     if rank == 0:
@@ -172,7 +174,8 @@ def sharded_leg(M, torch, dist, args, rank, world, dev, barrier, red_dev):
         ns1.solve()
         sec1 = time.perf_counter() - ts
         m1 = ns1.get_metrics()
-        out["single_gpu_same_pivots"] = {"pivots": m1["iterations"], "seconds": sec1, "us_per_pivot": sec1 / max(m1["iterations"], 1) * 1e6}
+        out["single_gpu_same_pivots"] = {"pivots": m1["iterations"], "seconds": sec1, "us_per_pivot": sec1 / max(m1["iterations"], 1) * 1e6,
+                                         "candidate_cache": bool(m1["engine"]["candidates"]), "searches_answered_on_the_host": m1["engine"]["host_decided"]}
         same = same and bool(np.array_equal(ns1.trace(), tr_host))
         del ns1
     barrier()
