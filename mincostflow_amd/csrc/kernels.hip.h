@@ -642,9 +642,10 @@ __device__ __forceinline__ void eval_tile_best2(const TileData<T> &d, const T *p
         const int64_t dd = (int64_t)d.c.v[j] + (int64_t)ps[j] - (int64_t)pt[j];
         const int64_t rc = st > 0 ? dd : (st < 0 ? -dd : 0);
         const uint32_t e = (uint32_t)(e0 + j);
-        const bool elig = rc < 0;
-        const bool b1 = elig && cand_less(rc, e, c1, p1);
-        const bool b2 = elig && !b1 && cand_less(rc, e, c2, p2);
+        // the arcs come in increasing id and c1, c2 start at 0 ("none"): an arc is better exactly when its key is strictly smaller
+        // (eligible <=> rc < 0, and an equal key keeps the lower id that is already there) -- two 64-bit compares per arc
+        const bool b1 = rc < c1;
+        const bool b2 = !b1 && rc < c2;
         // new best pushes the old best down to second
         c2 = b1 ? c1 : (b2 ? rc : c2);
         p2 = b1 ? p1 : (b2 ? e : p2);
@@ -656,7 +657,7 @@ __device__ __forceinline__ void eval_tile_best2(const TileData<T> &d, const T *p
 __device__ __forceinline__ void publish_candidates(int64_t c1, uint32_t p1, int64_t c2, uint32_t p2, Slot *slots, uint32_t tag)
 {
     const int tid = threadIdx.x;
-    __shared__ Cand wave_first[kResidentThreads / 64], wave_second[kResidentThreads / 64], out_rec[kCandRecords];
+    __shared__ Cand wave_first[kResidentThreads / 64], wave_second[kResidentThreads / 64];
     int64_t wc = c1;
     uint32_t wp = p1;
     cand_wave_min(wc, wp);                                   // the wave's best
@@ -665,37 +666,38 @@ __device__ __forceinline__ void publish_candidates(int64_t c1, uint32_t p1, int6
     cand_wave_min(sc, sp);                                   // the wave's exact second best
     if ((tid & 63) == 0) { wave_first[tid >> 6] = Cand{wc, wp}; wave_second[tid >> 6] = Cand{sc, sp}; }
     __syncthreads();
-    if (tid == 0) {
+    // Wave 0 folds the waves' records, one lane per wave: three butterflies take the kCandPerGroup best of the wave winners out one after the
+    // other, a fourth gives the threshold = the smallest key that is not reported (the winners left over and every wave's second best).
+    // (One thread walking the 16 waves' records took 4-5 us of every device search: a dependent chain of a thousand instructions on one lane.)
+    if (tid < 64) {
+        const int waves = (int)(blockDim.x >> 6);
+        int64_t fc = 0, tc = 0;
+        uint32_t fp = kNone, tp = kNone;
+        if (tid < waves) { fc = wave_first[tid].c; fp = wave_first[tid].p; tc = wave_second[tid].c; tp = wave_second[tid].p; }
         int64_t kc[kCandPerGroup];
         uint32_t kp[kCandPerGroup];
 #pragma unroll
-        for (int k = 0; k < kCandPerGroup; ++k) { kc[k] = 0; kp[k] = kNone; }
-        int64_t tc = 0;
-        uint32_t tp = kNone;                                 // threshold
-        const int waves = (int)(blockDim.x >> 6);
-        for (int w = 0; w < waves; ++w) {
-            int64_t c = wave_first[w].c;
-            uint32_t q = wave_first[w].p;
-            // insert (c, q) into the sorted top 4; whatever falls off goes to the threshold
-#pragma unroll
-            for (int k = 0; k < kCandPerGroup; ++k) {
-                const bool sw = cand_less(c, q, kc[k], kp[k]);
-                const int64_t oc = kc[k];
-                const uint32_t op = kp[k];
-                kc[k] = sw ? c : kc[k];
-                kp[k] = sw ? q : kp[k];
-                c = sw ? oc : c;
-                q = sw ? op : q;
-            }
-            if (cand_less(c, q, tc, tp)) { tc = c; tp = q; }
-            if (cand_less(wave_second[w].c, wave_second[w].p, tc, tp)) { tc = wave_second[w].c; tp = wave_second[w].p; }
+        for (int k = 0; k < kCandPerGroup; ++k) {
+            int64_t mc = fc;
+            uint32_t mp = fp;
+            cand_wave_min(mc, mp);
+            kc[k] = mc;
+            kp[k] = mp;
+            const bool mine = mp != kNone && fp == mp;       // arc ids are unique: exactly one lane holds the winner
+            fc = mine ? 0 : fc;
+            fp = mine ? kNone : fp;
         }
+        if (cand_less(fc, fp, tc, tp)) { tc = fc; tp = fp; }
+        cand_wave_min(tc, tp);
+        // kCandRecords lanes write the records = one whole 64-byte line; the threshold fills the rest of the line
+        if (tid < kCandRecords) {
+            int64_t oc = tc;
+            uint32_t op = tp;
 #pragma unroll
-        for (int k = 0; k < kCandPerGroup; ++k) { out_rec[k].c = kc[k]; out_rec[k].p = kp[k]; }
-        for (int k = kCandPerGroup; k < kCandRecords; ++k) { out_rec[k].c = tc; out_rec[k].p = tp; }     // threshold, repeated to fill the line
+            for (int k = 0; k < kCandPerGroup; ++k) { oc = tid == k ? kc[k] : oc; op = tid == k ? kp[k] : op; }
+            store_record_system(slots + (size_t)blockIdx.x * kCandRecords + tid, oc, op, tag);
+        }
     }
-    // kCandRecords lanes of wave 0 write the records = one whole 64-byte line (same wave as thread 0: LDS order is program order)
-    if (tid < kCandRecords) store_record_system(slots + (size_t)blockIdx.x * kCandRecords + tid, out_rec[tid].c, out_rec[tid].p, tag);
 }
 
 // Mailbox: lines of 64 bytes; dword 15 of EVERY line repeats seq, so a torn read of any line is detected and retried.
@@ -971,9 +973,9 @@ __device__ __forceinline__ void fold_rc_best2(uint32_t st4, const int64_t d[4], 
         const int st = (int)(int8_t)(st4 >> (8 * j));
         const int64_t rc = st > 0 ? d[j] : (st < 0 ? -d[j] : 0);
         const uint32_t e = (uint32_t)(e0 + j);
-        const bool elig = rc < 0;
-        const bool b1 = elig && cand_less(rc, e, c1, p1);
-        const bool b2 = elig && !b1 && cand_less(rc, e, c2, p2);
+        // a thread's arcs come in increasing id (within a tile and from trip to trip) and c1, c2 start at 0 ("none"): better <=> strictly smaller key
+        const bool b1 = rc < c1;
+        const bool b2 = !b1 && rc < c2;
         c2 = b1 ? c1 : (b2 ? rc : c2);
         p2 = b1 ? p1 : (b2 ? e : p2);
         c1 = b1 ? rc : c1;
