@@ -622,7 +622,8 @@ __device__ __forceinline__ void store_record_system(Slot *slot, int64_t c, uint3
 // = the smallest key among all of its eligible arcs that it does NOT report.  The host can then serve the following pivots
 // from the candidate list as long as the answer provably is on it (mcf_engine.cand_* in the host code) -- same pivots, fewer
 // round trips.  Per thread: best and second best of its 4 arcs; per wave: two butterflies give the wave's best and its exact
-// second best; thread 0 keeps the kCandPerGroup best of the wave winners and folds everything else into the threshold.
+// second best; wave 0 (one lane per wave) takes the kCandPerGroup best of the wave winners out with three more butterflies and folds
+// everything else into the threshold with a fourth.
 constexpr int kCandPerGroup = 3;
 constexpr int kCandRecords = 4;        // records per workgroup in candidate mode: 3 candidates + the threshold = one whole 64-byte line
 
