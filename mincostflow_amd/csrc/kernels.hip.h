@@ -627,15 +627,10 @@ __device__ __forceinline__ void store_record_system(Slot *slot, int64_t c, uint3
 constexpr int kCandPerGroup = 3;
 constexpr int kCandRecords = 4;        // records per workgroup in candidate mode: 3 candidates + the threshold = one whole 64-byte line
 
+// best and second best of a tile's four arcs, potentials already in registers
 template <typename T>
-__device__ __forceinline__ void eval_tile_best2(const TileData<T> &d, const T *pi, int e0, int64_t &c1, uint32_t &p1, int64_t &c2, uint32_t &p2,
-                                                int sub_node, T sub_val)
+__device__ __forceinline__ void fold_tile_best2(const TileData<T> &d, const T ps[4], const T pt[4], int e0, int64_t &c1, uint32_t &p1, int64_t &c2, uint32_t &p2)
 {
-    T ps[4], pt[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { ps[j] = pi[d.s.v[j]]; pt[j] = pi[d.t.v[j]]; }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { ps[j] = d.s.v[j] == sub_node ? sub_val : ps[j]; pt[j] = d.t.v[j] == sub_node ? sub_val : pt[j]; }
     c1 = 0; p1 = kNone; c2 = 0; p2 = kNone;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -653,6 +648,18 @@ __device__ __forceinline__ void eval_tile_best2(const TileData<T> &d, const T *p
         c1 = b1 ? rc : c1;
         p1 = b1 ? e : p1;
     }
+}
+
+template <typename T>
+__device__ __forceinline__ void eval_tile_best2(const TileData<T> &d, const T *pi, int e0, int64_t &c1, uint32_t &p1, int64_t &c2, uint32_t &p2,
+                                                int sub_node, T sub_val)
+{
+    T ps[4], pt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ps[j] = pi[d.s.v[j]]; pt[j] = pi[d.t.v[j]]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ps[j] = d.s.v[j] == sub_node ? sub_val : ps[j]; pt[j] = d.t.v[j] == sub_node ? sub_val : pt[j]; }
+    fold_tile_best2<T>(d, ps, pt, e0, c1, p1, c2, p2);
 }
 
 __device__ __forceinline__ void publish_candidates(int64_t c1, uint32_t p1, int64_t c2, uint32_t p2, Slot *slots, uint32_t tag)
@@ -711,7 +718,7 @@ __device__ __forceinline__ void publish_candidates(int64_t c1, uint32_t p1, int6
 //   line 1..    five entries {a, b, c} each: potential patches 1..n_pi-1 {node, lo, hi}, then state patches 2..n_st-1 {arc, value, 0}
 // The poll reads line 0 only (one 64-byte read per workgroup per poll); the other lines are fetched when there are more entries.
 //
-// PIREG (register-resident arcs, potentials not in LDS, no candidate list, at most kPiRegThreads threads): a thread also keeps the potentials of its arcs' end points in
+// PIREG (register-resident arcs, potentials not in LDS, at most kPiRegThreads threads; with or without the candidate list): a thread also keeps the potentials of its arcs' end points in
 // registers and PATCHES them instead of gathering them again for every request -- the eight divergent gathers per thread cost
 // ~1.5 us per request on a CU (one lane per clock) while three out of four pivots move five nodes or fewer.  Lists of up to
 // kPiRegCompare entries are compared against the eight end points directly (LDS broadcast reads); up to one chunk goes through a
@@ -726,7 +733,7 @@ template <typename T, int RULE, bool OPT, bool REG, bool LPI, bool CAND, bool PI
 __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resident_kernel(const ResidentParams<T> p)
 {
     static_assert(!PERM || (RULE == MCF_RULE_BEST_ELIGIBLE && !REG && !LPI && !CAND), "the bucketed layout serves the tile loop of Best Eligible");
-    static_assert(!PIREG || (REG && !LPI && !CAND), "PIREG needs register-resident arcs and global potentials");
+    static_assert(!PIREG || (REG && !LPI), "PIREG needs register-resident arcs and global potentials");
     // mailbox staging: line 0 + one chunk of patch lines: 16 KB next to LDS-resident potentials, else 32 KB (2555 entries per chunk);
     // kept small so that several resident grids (independent solves) can share a CU
     constexpr int kLines = LPI ? kMailboxLines : 2 * kMailboxLines, kChunk = kLines - 1;
@@ -922,7 +929,8 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
         if (CAND) {
             int64_t c1, c2;
             uint32_t p1, p2;
-            eval_tile_best2<T>(mine, pi_view, p.base + my_i0, c1, p1, c2, p2, sub_node, v0);
+            if (PIREG) fold_tile_best2<T>(mine, ps, pt, p.base + my_i0, c1, p1, c2, p2);
+            else eval_tile_best2<T>(mine, pi_view, p.base + my_i0, c1, p1, c2, p2, sub_node, v0);
             publish_candidates(c1, p1, c2, p2, p.slots, seq);
         } else {
             Key best;

@@ -70,6 +70,8 @@ void launch_resident_r(mcf_engine *e, const ResidentParams<T> &p)
     const bool lpi = e->lds_pi;
     if (e->cand_on) {     // candidates: Best Eligible, register-resident tiles only
         if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, true, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+        else if (e->res_threads <= kPiRegThreads && !e->no_pireg)       // the end points' potentials stay in registers between the requests
+            hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, false, true, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
         else hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, false, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
     }
     else if (e->resident_reg && lpi) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, true, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
