@@ -1087,6 +1087,8 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
         if (const char *u = getenv("MCF_HIP_CAND_NODES")) { const int v = atoi(u); if (v >= 0 && v <= 4096) e->cand_max_nodes = v; }
         if (const char *u = getenv("MCF_HIP_CAND_REFRESH")) { const int v = atoi(u); if (v >= 0 && v <= 4096) e->cand_refresh_low = v; }
     }
+    // the pending lists grow to a subtree's size: get (and touch) their memory now, not in the middle of a solve
+    e->pend_node.assign((size_t)e->patch_capacity, 0); e->pend_val.assign((size_t)e->patch_capacity, 0);
     e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
     e->next_arc = 0;
     e->uploaded = true;
