@@ -186,6 +186,15 @@ MCF_API int mcf_engine_shift_potential(mcf_engine *e, int32_t count, const int32
  * own up to date.  Contract: when a search begins the array holds the values announced by set / append / shift_potential since the last
  * search, and it does not change while a search is in flight.  mcf_engine_update_potential (+= sigma) is not available while bound. */
 MCF_API int mcf_engine_bind_potentials(mcf_engine *e, const int64_t *pi);
+/* Bound potentials, layouts that keep reduced costs per arc: when a pivot moves a large part of the tree, naming the nodes costs more than
+ * handing the whole array over.  mcf_engine_reload_threshold: *min_nodes = the list length from which a reload is the cheaper call for this
+ * engine (0: the engine only takes lists -- no binding, potentials kept in registers / LDS, 32-bit potentials).  mcf_engine_reload_potentials:
+ * "the bound array is current, `changed_nodes` of its entries differ from what you last heard" (the count only feeds the statistics); it
+ * replaces every set / append / shift_potential call since the last search, is ordered before the next search like them, and the array must
+ * stay unchanged until that search has been answered.  The engine copies the array to the device by itself (the binding registered it with HIP)
+ * and computes every reduced cost of its shard again (NS.cs:1185-1209 moves the same values; what reaches the device is the result). */
+MCF_API int mcf_engine_reload_threshold(mcf_engine *e, int32_t *min_nodes);
+MCF_API int mcf_engine_reload_potentials(mcf_engine *e, int32_t changed_nodes);
 
 /* Rewrites (source, target, cost) of arcs, e.g. artificial arcs re-pointed by a warm start. Synchronous. */
 MCF_API int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, const int32_t *source,

@@ -280,7 +280,7 @@ int cand_post_rc(mcf_engine *e)
     const size_t n_b = e->blind_count, n_s = e->rc_sync.size();
     const bool blind_ok = n_b == 0 || (e->pend_shift && e->blind_epoch == e->cand_now);      // shifts add up: a node may sit in both lists
     const int64_t n_st = (int64_t)e->sync_arcs.size();
-    const bool fast = !e->rc_shift_unknown && blind_ok && (int64_t)(n_b + n_s) <= kRcResidentNodes && n_st <= e->mailbox_max_st &&
+    const bool fast = !e->reload_pi && !e->rc_shift_unknown && blind_ok && (int64_t)(n_b + n_s) <= kRcResidentNodes && n_st <= e->mailbox_max_st &&
                       (int64_t)(n_b + n_s > 1 ? n_b + n_s - 1 : 0) + (n_st > 2 ? n_st - 2 : 0) <= (int64_t)(kMailboxLines - 1) * kMailboxPatchesPerLine;
     if (fast) {
         e->pend_node.resize(n_b + n_s);

@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -128,6 +129,8 @@ struct mcf_engine {
     // host mirror of pi: patches carry final values
     mcf::hvec<int64_t> pi;
     bool mirror_valid = false;     // mcf_engine_set_potential stops maintaining the mirror; update_potential rebuilds it on demand
+    bool ext_pi_pinned = false, ext_pi_pin_owner = false;   // the bound array is registered with HIP (the device can copy it by itself): mcf_engine_reload_potentials
+    bool reload_pi = false;            // the whole bound array is to be copied to the device before the next search (and the RC layout recomputed)
     const int64_t *ext_pi = nullptr;   // mcf_engine_bind_potentials: the caller's own array is read instead of the mirror (no second copy to keep up to date)
     int64_t max_abs_cost = 0;
     // pending patches of the current pivot
@@ -465,8 +468,19 @@ int flush_pending(mcf_engine *e)
     // candidate mode keeps what the device has not heard yet as lists of nodes / arcs: turn them into patches (current values from the mirrors).
     // The list and the heap stay valid: they are bookkeeping about epochs, not about what the device knows.
     if (e->cand_on && (!e->sync_nodes.empty() || !e->sync_arcs.empty() || e->blind_count > 0)) { const int rcb = cand_build_patches(e); if (rcb) return rcb; }
+    const bool reload = e->reload_pi;
+    if (reload) {
+        // mcf_engine_reload_potentials: the caller's whole array instead of lists (whatever was noted since is part of it), then -- below, after
+        // the state writes -- every reduced cost of the shard again
+        e->pend_node.clear(); e->pend_val.clear();
+        HIP_TRY(hipMemcpyAsync(e->d_pi, e->ext_pi, sizeof(int64_t) * (size_t)e->d.node_count, hipMemcpyHostToDevice, e->stream));
+        e->reload_pi = false;
+    }
     const int n_pi_all = (int)e->pend_node.size(), n_st_all = (int)e->pend_arc.size();
-    if (n_pi_all == 0 && n_st_all == 0) return MCF_OK;
+    if (n_pi_all == 0 && n_st_all == 0) {
+        if (reload) { if (int rcr = rc_recompute(e)) return rcr; e->st.rc_recomputes += 1; }
+        return MCF_OK;
+    }
     // the staging buffers hold kStageStates state patches: longer lists go out in rounds (the potentials ride in the first)
     for (int st0 = 0, round = 0; round == 0 || st0 < n_st_all; st0 += kStageStates, ++round) {
         const int n_pi = round == 0 ? n_pi_all : 0, n_st = std::min(kStageStates, n_st_all - st0);
@@ -507,6 +521,7 @@ int flush_pending(mcf_engine *e)
         e->st.update_launches += 1;
     }
     e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
+    if (reload) { if (int rcr = rc_recompute(e)) return rcr; e->st.rc_recomputes += 1; }
     return MCF_OK;
 }
 
@@ -597,7 +612,7 @@ int search_begin(mcf_engine *e)
         if (e->rc_mode) {
             // resident RC grid: a request is one staging chunk of {node, shift} entries; anything else goes through update_rc_kernel with the grid stopped
             const int64_t n_pi = (int64_t)e->pend_node.size(), n_st = (int64_t)e->pend_arc.size();
-            fits = (n_pi == 0 || e->pend_shift) && n_pi <= kRcResidentNodes &&
+            fits = !e->reload_pi && (n_pi == 0 || e->pend_shift) && n_pi <= kRcResidentNodes &&
                    (n_pi > 1 ? n_pi - 1 : 0) + (n_st > 2 ? n_st - 2 : 0) <= (int64_t)(kMailboxLines - 1) * kMailboxPatchesPerLine;
             if (fits && n_pi > 0) std::fill(e->pend_val.begin(), e->pend_val.end(), e->pend_sigma);      // the entries carry the shift, not the value
         }
@@ -627,7 +642,7 @@ int search_begin(mcf_engine *e)
     if (e->seq == 0) e->seq = 1;
     // RC layout: a potential change is a shift of the reduced costs of the node's arcs.  A short list with one common shift rides in the
     // scan's arguments (every workgroup shifts the arcs it scans itself); anything else goes through update_rc_kernel first
-    const bool inline_ok = !(e->d.flags & MCF_ENGINE_NO_INLINE_UPDATE) && (e->rc_mode ? rc_inline_ok(e) : (int)e->pend_node.size() <= kInlinePi) &&
+    const bool inline_ok = !(e->d.flags & MCF_ENGINE_NO_INLINE_UPDATE) && !e->reload_pi && (e->rc_mode ? rc_inline_ok(e) : (int)e->pend_node.size() <= kInlinePi) &&
                            (int)e->pend_arc.size() <= kInlineState;
     if (!inline_ok) { int rc = flush_pending(e); if (rc) return rc; }
     const bool timed = (e->d.flags & MCF_ENGINE_TIME_EVERY_KERNEL) ||
@@ -961,6 +976,34 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
     return MCF_OK;
 }
 
+namespace {
+// Host arrays registered with HIP on behalf of the engines that bind them (several engines of one solver bind the same array): one
+// registration per array, given back when the last engine lets go of it.
+std::mutex g_pin_mutex;
+std::map<const void *, int> g_pins;
+bool host_pin(const void *p, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    auto it = g_pins.find(p);
+    if (it != g_pins.end()) { it->second += 1; return true; }
+    const hipError_t r = hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterPortable);
+    (void)hipGetLastError();                      // a refusal is not an error of the engine: it then takes node lists only
+    if (r != hipSuccess) return false;
+    g_pins[p] = 1;
+    return true;
+}
+void host_unpin(const void *p)
+{
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    auto it = g_pins.find(p);
+    if (it == g_pins.end()) return;
+    if (--it->second > 0) return;
+    g_pins.erase(it);
+    (void)hipHostUnregister(const_cast<void *>(p));
+    (void)hipGetLastError();
+}
+}  // namespace
+
 void mcf_engine_destroy(mcf_engine *e)
 {
     if (!e) return;
@@ -974,6 +1017,7 @@ void mcf_engine_destroy(mcf_engine *e)
     }
     (void)hipSetDevice(e->d.device);
     if (e->resident_running) (void)resident_stop(e);
+    if (e->ext_pi && e->ext_pi_pinned) { if (e->stream) (void)hipStreamSynchronize(e->stream); host_unpin(e->ext_pi); }
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->mailbox) hsa_amd_memory_pool_free(e->mailbox);
     if (e->h_exit) (void)hipHostFree(e->h_exit);
@@ -1245,8 +1289,50 @@ int mcf_engine_bind_potentials(mcf_engine *e, const int64_t *pi)
 {
     if (!e) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_bind_potentials: null engine");
     if (e->in_flight != mcf_engine::kNoSearch) return mcf::fail(MCF_ERR_STATE, "mcf_engine_bind_potentials: a search is in flight");
+    if (e->ext_pi && e->ext_pi_pinned) host_unpin(e->ext_pi);
+    e->ext_pi_pinned = e->ext_pi_pin_owner = false;
+    e->reload_pi = false;
     e->ext_pi = pi;
     if (!pi) e->mirror_valid = false;
+    // RC layout, 64-bit potentials: the array is made known to HIP so that a reload (mcf_engine_reload_potentials) is one asynchronous copy.
+    // Several engines of one solver bind the same array: the first registers it, the others find it registered.
+    if (pi && e->rc_mode && e->d.int_width == 64) {
+        (void)hipSetDevice(e->d.device);
+        e->ext_pi_pinned = host_pin(pi, sizeof(int64_t) * (size_t)e->d.node_count);
+    }
+    return MCF_OK;
+}
+
+int mcf_engine_reload_threshold(mcf_engine *e, int32_t *min_nodes)
+{
+    if (!e || !min_nodes) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_reload_threshold: null argument");
+    *min_nodes = (e->rc_mode && e->ext_pi && e->ext_pi_pinned && e->rc_recompute_above < INT32_MAX) ? e->rc_recompute_above + 1 : 0;
+    return MCF_OK;
+}
+
+int mcf_engine_reload_potentials(mcf_engine *e, int32_t changed_nodes)
+{
+    if (!e || changed_nodes < 0) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_reload_potentials: bad arguments");
+    if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
+    if (!(e->rc_mode && e->ext_pi && e->ext_pi_pinned)) return mcf::fail(MCF_ERR_STATE, "mcf_engine_reload_potentials: this engine takes node lists (see mcf_engine_reload_threshold)");
+    if (e->in_flight == mcf_engine::kResidentSearch || e->in_flight == mcf_engine::kCandSearch || e->in_flight == mcf_engine::kDispatchSearch) {
+        // the array must not change while a search reads from it: the caller is between two searches by contract; an answered one may still wait to be fetched
+        return mcf::fail(MCF_ERR_STATE, "mcf_engine_reload_potentials: a search is in flight");
+    }
+    // every potential change that is still waiting for the device is part of the array: the lists are dropped, the state writes stay
+    if (e->stream_lines > 0) { const int rc = resident_stop(e); if (rc) return rc; }
+    e->pend_node.clear(); e->pend_val.clear();
+    e->pend_shift = false;
+    if (e->cand_on) {
+        e->pivot_overflow = true;           // nothing is evaluated on the host: the device searches next (cand_absorb_pivot notes the gap)
+        e->sync_nodes.clear();
+        e->rc_sync.clear();
+        e->rc_shift_unknown = false;
+        e->blind_count = 0;
+    }
+    e->reload_pi = true;
+    e->mirror_valid = false;
+    e->st.potential_nodes += changed_nodes;
     return MCF_OK;
 }
 

@@ -63,7 +63,11 @@ struct mcf_ns {
     mcf::hvec<int64_t> moved_val;   // their new potentials
     int moved_n = 0;
     bool shift_smaller_side = false;  // inside mcf_ns_solve with 64-bit engines: see shift_potentials
+    int reload_min = 0;               // inside mcf_ns_solve: walks of at least this many nodes are announced as a reload of _pi (0: never)
+    int reload_min_engines = 0;       // what the engines asked for (mcf_engine_reload_threshold), 0 when one of them only takes lists
+    bool moved_as_reload = false;     // the last walk wrote no node list: the engines reload _pi
     bool allow_smaller_side = false;
+    int64_t dbg_reload_walks = 0;
     int64_t dbg_hist_n[32] = {0}, dbg_hist_nodes[32] = {0}, dbg_over_half = 0, dbg_over_half_nodes = 0;   // MCF_NS_DEBUG: subtree sizes by log2
     int moved_sent = 0;               // how many of them the engine already has (handed over during the walk)
     int engine_rc = 0;                // first error of an engine call made from inside a pivot
@@ -103,6 +107,12 @@ int engines_append_potential(mcf_ns *s, int32_t count, const int32_t *nodes, con
 {
     int rc = mcf_engine_shift_potential(s->engine, count, nodes, values, s->sigma); // the potentials are replicated on every shard
     for (size_t i = 0; i < s->peers.size() && !rc; ++i) rc = mcf_engine_shift_potential(s->peers[i], count, nodes, values, s->sigma);
+    return rc;
+}
+int engines_reload_potentials(mcf_ns *s, int32_t changed)
+{
+    int rc = mcf_engine_reload_potentials(s->engine, changed);
+    for (size_t i = 0; i < s->peers.size() && !rc; ++i) rc = mcf_engine_reload_potentials(s->peers[i], changed);
     return rc;
 }
 int engines_search_begin(mcf_ns *s)
@@ -401,6 +411,30 @@ void shift_potentials(mcf_ns *s)
     }
     const int64_t sigma = s->sigma;
     s->moved_n = count;
+    s->moved_as_reload = false;
+    if (s->reload_min > 0 && count >= s->reload_min) {
+        // A walk this long is cheaper for the engines as "reload _pi" than as a list (mcf_engine_reload_potentials): nothing is written down,
+        // the walk only moves the potentials.  The hints need the node kWalkAhead steps back: a ring of that many.
+        int64_t *const pi = s->pi.data();
+        const int32_t *const nxt = s->nxt.data();
+        int32_t *const follow = s->follow.data();
+        int32_t ring[kWalkAhead];
+        int a = first;
+        for (int i = 0; i < count; ++i) {
+            const int h = follow[a];
+            __builtin_prefetch(&nxt[h]);
+            __builtin_prefetch(&pi[h]);
+            __builtin_prefetch(&follow[h]);
+            pi[a] += sigma;
+            if (i >= kWalkAhead) follow[ring[i & (kWalkAhead - 1)]] = a;
+            ring[i & (kWalkAhead - 1)] = a;
+            a = nxt[a];
+        }
+        s->moved_as_reload = true;
+        s->moved_sent = count;
+        s->dbg_reload_walks += 1;
+        return;
+    }
     int32_t *const nodes = s->moved.data();
     int64_t *const vals = s->moved_val.data();
     int64_t *const pi = s->pi.data();
@@ -458,6 +492,13 @@ int normalise_potentials(mcf_ns *s)
     const int64_t off = s->pi[s->root];
     if (off == 0) return MCF_OK;
     const int total = s->n + 1;
+    if (s->reload_min > 0) {
+        for (int u = 0; u < total; ++u) s->pi[u] -= off;
+        s->sigma = -off;
+        s->moved_n = total;
+        s->moved_sent = total;
+        return engines_reload_potentials(s, total);
+    }
     for (int u = 0; u < total; ++u) { s->moved[u] = u; s->moved_val[u] = (s->pi[u] -= off); }
     s->sigma = -off;
     s->moved_n = total;
@@ -823,6 +864,19 @@ int mcf_ns_prepare(mcf_ns *s)
         rc = mcf_engine_bind_potentials(e, s->pi.data());       // this solver's _pi is current whenever a search begins and still while it is in flight
         if (rc) return rc;
     }
+    {
+        // every engine of the solver has to agree to reloads (they all follow the same potentials): the largest of their thresholds, or none
+        int32_t lo = 0;
+        bool all = !(getenv("MCF_NS_RELOAD") && getenv("MCF_NS_RELOAD")[0] == '0');
+        for (int r = 0; r < shards && all; ++r) {
+            int32_t v = 0;
+            rc = mcf_engine_reload_threshold(r == 0 ? s->engine : s->peers[r - 1], &v);
+            if (rc) return rc;
+            if (v <= 0) all = false;
+            lo = std::max(lo, v);
+        }
+        s->reload_min_engines = all ? std::max<int32_t>(lo, kWalkHintMin) : 0;
+    }
     s->cands.assign((size_t)std::max(1, s->world), mcf_candidate{0, 0xFFFFFFFFu, -1});
     if (s->shard_mode == mcf_ns::kHost) { rc = mcf_exchange_open(&s->exchange, s->exchange_name.c_str(), s->rank, s->world); if (rc) return rc; }
     s->metrics.config_flags = s->config.flags;
@@ -859,6 +913,7 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     s->engine_rc = 0;
     s->piece_ticks = 0;
     s->shift_smaller_side = s->allow_smaller_side;
+    s->reload_min = s->reload_min_engines;
     // The search for pivot k+1 is posted as soon as the device has what it depends on (State[] writes, potentials); the rest of pivot k
     // (flows around the cycle, re-hanging the subtree) runs while the device is searching.  Engines sharded over RCCL search in one
     // blocking call (the all-gather runs on their stream), so for them the two halves simply follow each other.
@@ -876,7 +931,8 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         if (pivot_front(s, arc, &t_pot)) { s->status = MCF_UNBOUNDED; break; }
         const double t1 = ticks();
         rc = s->engine_rc;
-        if (!rc && s->moved_n > s->moved_sent)
+        if (!rc && s->moved_as_reload) rc = engines_reload_potentials(s, (int32_t)s->moved_n);
+        else if (!rc && s->moved_n > s->moved_sent)
             rc = engines_append_potential(s, (int32_t)(s->moved_n - s->moved_sent), s->moved.data() + s->moved_sent, s->moved_val.data() + s->moved_sent);
         const double t2 = ticks();
         if (!rc) rc = engines_search_begin(s);
@@ -894,6 +950,7 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     s->hand_over = false;
     s->shift_smaller_side = false;
     if (!rc) rc = normalise_potentials(s);
+    s->reload_min = 0;
     const char *first_error = rc ? mcf_last_error() : nullptr;
     std::string keep_error = first_error ? first_error : "";
     engines_park(s);                 // a resident scan grid must not outlive Solve()
@@ -912,7 +969,8 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     if (getenv("MCF_NS_DEBUG") && it > 1000) {
         fprintf(stderr, "[ns] moved subtrees by size (pivots / nodes):");
         for (int b = 0; b < 32; ++b) if (s->dbg_hist_n[b]) fprintf(stderr, " 2^%d: %lld / %lld |", b, (long long)s->dbg_hist_n[b], (long long)s->dbg_hist_nodes[b]);
-        fprintf(stderr, " more than half of the %d nodes: %lld / %lld\n", s->n, (long long)s->dbg_over_half, (long long)s->dbg_over_half_nodes);
+        fprintf(stderr, " more than half of the %d nodes: %lld / %lld | walks announced as a reload of _pi (%d nodes and more): %lld\n", s->n, (long long)s->dbg_over_half,
+                (long long)s->dbg_over_half_nodes, s->reload_min_engines, (long long)s->dbg_reload_walks);
     }
     mcf_engine_get_stats(s->engine, &s->metrics.engine);
     // the rest of SolverMetrics: NS.cs:262-270 (initial block size), :276 (expected iterations), :344-357

@@ -378,6 +378,24 @@ class PivotEngine:
         nodes, values = _i32(nodes), _i64(values)
         L.check(L.lib().mcf_engine_shift_potential(self._h, nodes.shape[0], nodes, values, sigma))
 
+    def bind_potentials(self, pi):
+        """mcf_engine_bind_potentials: `pi` (int64[node_count], C-contiguous) is read in place from now on; the caller keeps it alive and current."""
+        if pi is None:
+            self._bound_pi = None
+            L.check(L.lib().mcf_engine_bind_potentials(self._h, None))
+            return
+        assert pi.dtype == np.int64 and pi.flags["C_CONTIGUOUS"]
+        self._bound_pi = pi
+        L.check(L.lib().mcf_engine_bind_potentials(self._h, pi.ctypes.data))
+
+    def reload_threshold(self) -> int:
+        v = C.c_int32(0)
+        L.check(L.lib().mcf_engine_reload_threshold(self._h, C.byref(v)))
+        return v.value
+
+    def reload_potentials(self, changed_nodes: int):
+        L.check(L.lib().mcf_engine_reload_potentials(self._h, changed_nodes))
+
     def patch_arcs(self, arcs, source, target, cost):
         arcs = _i32(arcs)
         L.check(L.lib().mcf_engine_patch_arcs(self._h, len(arcs), arcs, _i32(source), _i32(target), _i64(cost)))

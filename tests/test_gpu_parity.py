@@ -629,6 +629,77 @@ def test_arc_shards_keep_their_own_candidate_caches(layout, monkeypatch):
         assert np.array_equal(e.download_state()[b:en], a["state"][b:en])
 
 
+RC_MODES = [pytest.param("rc", id="rc-layout"), pytest.param("rc-resident", id="rc-resident-lds"), pytest.param("rc-stream", id="rc-resident-stream"),
+            pytest.param("rc-cand", id="rc-candidates-lds"), pytest.param("rc-cand-stream", id="rc-candidates-stream")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", RC_MODES)
+def test_reload_of_the_bound_potentials_replaces_node_lists(mode, monkeypatch):
+    """mcf_engine_bind_potentials + mcf_engine_reload_potentials (RC layout): after changes to a large part of the caller's array the engine is told
+    'reload' instead of being handed the nodes; it copies the array by itself and computes every reduced cost again.  Mixed with ordinary lists
+    and state writes, with further small lists between the reload and the search, in every RC engine mode: the oracle's answer every time."""
+    flags = _mode_flags(mode, monkeypatch)
+    rng = np.random.default_rng(4711)
+    m_s, n = 120_003, 25_000
+    a = _random_soa(rng, m_s, n, 30, 200, extra=0)
+    eng = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible, optimized=True, flags=flags)
+    eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+    assert eng.reload_threshold() == 0                      # nothing bound yet: lists only
+    eng.bind_potentials(a["pi"])
+    lo = eng.reload_threshold()
+    assert lo == max(1024, n // 16) + 1
+    for it in range(40):
+        f, arc, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+        assert eng.find_entering() == (f, arc, c), it
+        arcs = rng.choice(m_s, size=2, replace=False).astype(np.int32); vals = rng.integers(-1, 2, 2).astype(np.int8)
+        a["state"][arcs] = vals
+        eng.patch_state(arcs, vals)
+        kind = it % 4
+        if kind == 0:                                        # an ordinary list
+            nodes = rng.choice(n, size=int(rng.choice([1, 30, 2000])), replace=False).astype(np.int32)
+            sigma = int(rng.integers(-9, 10))
+            a["pi"][nodes] += sigma
+            eng.shift_potential(nodes, a["pi"][nodes], sigma)
+        else:                                                # a large part of the array changes in place; the engine only hears "reload"
+            k = int(rng.choice([lo, n // 2, n - 1]))
+            nodes = rng.choice(n, size=k, replace=False)
+            a["pi"][nodes] += int(rng.integers(-9, 10))
+            if kind == 2:                                    # ... after a list that the reload makes redundant
+                few = rng.choice(n, size=5, replace=False).astype(np.int32)
+                a["pi"][few] -= 1
+                eng.shift_potential(few, a["pi"][few], -1)
+                a["pi"][nodes] += 2
+            eng.reload_potentials(k)
+            if kind == 3:                                    # ... and a small list on top of it before the search
+                few = rng.choice(n, size=3, replace=False).astype(np.int32)
+                a["pi"][few] += 4
+                eng.shift_potential(few, a["pi"][few], 4)
+    f, arc, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+    assert eng.find_entering() == (f, arc, c)
+    st = eng.stats()
+    assert st["rc_layout"] == 1 and st["rc_recomputes"] >= 25
+    assert np.array_equal(eng.download_pi(), a["pi"]) and np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
+    eng.bind_potentials(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", RC_MODES)
+@pytest.mark.parametrize("name", ["netgen_8_10a", "AURV19V6"])
+def test_solve_that_reloads_the_potentials_after_long_walks(name, mode, monkeypatch):
+    """mcf_ns_solve over the RC layout with the reload threshold lowered to 48 nodes (default: a sixteenth of the nodes): every longer walk
+    moves the potentials without writing a list and the engines reload _pi -- same pivots, flows and potentials as the oracle."""
+    flags = _mode_flags(mode, monkeypatch)
+    monkeypatch.setenv("MCF_HIP_RC_RECOMPUTE", "8")
+    p = load(name)
+    o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, O.RULE_BEST, int_width=64, flags=flags)      # reloads copy int64 potentials: 64-bit engines only
+    assert st == st_o == O.OPTIMAL and np.array_equal(ns.trace(), tr_o)
+    assert ns.get_total_cost() == o.total_cost
+    assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
+    m = ns.get_metrics()
+    assert m["engine"]["rc_layout"] == 1 and m["engine"]["rc_recomputes"] > 50
+
+
 @pytest.mark.gpu
 def test_register_resident_potentials_pivot_for_pivot():
     """A solve bigger than the bundled fixtures (20k nodes / 60k arcs: the potentials do not fit LDS), so the resident grid keeps the end
