@@ -129,7 +129,7 @@ struct mcf_engine {
     // host mirror of pi: patches carry final values
     mcf::hvec<int64_t> pi;
     bool mirror_valid = false;     // mcf_engine_set_potential stops maintaining the mirror; update_potential rebuilds it on demand
-    bool ext_pi_pinned = false, ext_pi_pin_owner = false;   // the bound array is registered with HIP (the device can copy it by itself): mcf_engine_reload_potentials
+    bool ext_pi_pinned = false;        // the bound array is registered with HIP (the device can copy it by itself): mcf_engine_reload_potentials
     bool reload_pi = false;            // the whole bound array is to be copied to the device before the next search (and the RC layout recomputed)
     const int64_t *ext_pi = nullptr;   // mcf_engine_bind_potentials: the caller's own array is read instead of the mirror (no second copy to keep up to date)
     int64_t max_abs_cost = 0;
@@ -1290,7 +1290,7 @@ int mcf_engine_bind_potentials(mcf_engine *e, const int64_t *pi)
     if (!e) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_bind_potentials: null engine");
     if (e->in_flight != mcf_engine::kNoSearch) return mcf::fail(MCF_ERR_STATE, "mcf_engine_bind_potentials: a search is in flight");
     if (e->ext_pi && e->ext_pi_pinned) host_unpin(e->ext_pi);
-    e->ext_pi_pinned = e->ext_pi_pin_owner = false;
+    e->ext_pi_pinned = false;
     e->reload_pi = false;
     e->ext_pi = pi;
     if (!pi) e->mirror_valid = false;
