@@ -14,7 +14,7 @@ def solve(label, env, pivots):
     ns = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).set_device(0, 64, 0, 0)
     if pivots:
         ns.set_pivot_limit(pivots)
-    ns.record_trace(20000).prepare()
+    ns.record_trace(int(os.environ.get("RC_TRACE", "20000"))).prepare()          # RC_TRACE=3000000: the whole solve's entering arcs are compared
     t0 = time.perf_counter()
     ns.solve()
     wall = time.perf_counter() - t0
@@ -30,5 +30,9 @@ def solve(label, env, pivots):
 for pivots in [int(x) for x in sys.argv[1:]] or [100000]:
     b = solve("candidate", {}, pivots)
     if os.environ.get("RC_CAND_ONLY") != "1":
-        a = solve("device   ", {"MCF_HIP_CANDIDATES": 0}, pivots)
+        plain = {"MCF_HIP_CANDIDATES": 0}
+        if os.environ.get("RC_PLAINEST") == "1":      # ... and none of the host driver's short cuts either: every walk is the subtree's, every list is named and shifted arc by arc
+            plain.update({"MCF_NS_RELOAD": 0, "MCF_NS_SMALLER_SIDE": 0, "MCF_HIP_RC_RECOMPUTE": 0})
+        a = solve("device   ", plain, pivots)
         assert np.array_equal(a, b)
+        print(f"entering arcs compared: {len(a)} of each run, identical", flush=True)
