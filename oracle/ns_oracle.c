@@ -23,7 +23,10 @@
  *                      rules, auto-configuration off (fixed block size)
  *   NSO_SEM_CSHARP_OPT same host driver, pivot rules of
  *                      .../Algorithms/Internal/BlockSearchPivotOptimized.cs
- *                      (what EnableOptimizedPivot(true) selects)
+ *                      (what EnableOptimizedPivot(true) selects), with the vector width V of the
+ *                      reference's host (nso_set_vector_width; default 4 = x64): for V > 0 the Block
+ *                      Search there scans to the end of the range after a hit in its "SIMD" part
+ *                      (BSPO.cs:84-99 falls through with cnt == 0), V = 0 is the scalar-only path
  *
  * Every function cites the reference lines it follows.  "NS.cs" below means
  * src/MinCostFlow.Core/Lemon/Algorithms/NetworkSimplex.cs, "ns.h" means
@@ -67,6 +70,7 @@ typedef struct ns_oracle {
     int64_t delta;
     /* pivot-rule state */
     int next_arc, block_size, block_size_req;
+    int vector_width;                /* BSPO.cs:74,115: Vector<long>.Count of the reference's host; 0 = not hardware accelerated */
     /* OptimizationConfig (OptimizationTypes.cs:24-38), consumed by the plain C# BlockSearchPivot only */
     int cfg_flags, cfg_min_block, cfg_max_block, cfg_consec;
     double cfg_ratio, cfg_grow, cfg_shrink, cfg_low, cfg_high;
@@ -130,6 +134,7 @@ NSO_API ns_oracle *nso_create(int n, int m, const int32_t *src, const int32_t *t
     /* new OptimizationConfig(): OptimizationTypes.cs:26-37 */
     o->cfg_flags = 0; o->cfg_max_block = 100; o->cfg_min_block = 25; o->cfg_grow = 1.2; o->cfg_shrink = 0.8;
     o->cfg_low = 0.05; o->cfg_high = 0.3; o->cfg_consec = 3; o->cfg_ratio = 0.125;
+    o->vector_width = 4;             /* x64 with AVX2 (and .NET 8 on AVX-512 hardware): Vector<long>.Count == 4 */
     return o;
 }
 
@@ -140,6 +145,13 @@ NSO_API void nso_set_config(ns_oracle *o, int flags, int min_block, int max_bloc
     o->cfg_flags = flags; o->cfg_min_block = min_block; o->cfg_max_block = max_block; o->cfg_consec = consec;
     o->cfg_ratio = ratio; o->cfg_grow = grow; o->cfg_shrink = shrink; o->cfg_low = low; o->cfg_high = high;
     o->auto_config = 0;
+}
+/* the reference has no such setter: Vector<long>.Count is a property of the machine it runs on (BSPO.cs:74, :115) */
+NSO_API int nso_set_vector_width(ns_oracle *o, int v)
+{
+    if (v != 0 && v != 2 && v != 4 && v != 8) return 0;
+    o->vector_width = v;
+    return 1;
 }
 /* SetAutoConfiguration (NS.cs:567-570) */
 NSO_API void nso_set_auto_config(ns_oracle *o, int enable) { o->auto_config = enable; }
@@ -475,28 +487,56 @@ search_end:
     return 1;
 }
 
-/* BSPO.cs:69-110 ProcessArcRange (the "SIMD" branch :113-156 is the same scalar loop, F7) */
-static int opt_range(ns_oracle *o, int start, int end, int64_t *min, int *cnt, int *best)
+/* BSPO.cs:69-156 ProcessArcRange + ProcessArcRangeSIMD on bare arrays.  V = Vector<long>.Count of the host the reference runs on
+ * (4 on AVX2 / AVX-512 x64 under .NET 8, 2 on NEON), 0 = Vector.IsHardwareAccelerated == false.
+ * The "SIMD" function (BSPO.cs:113-156) is a scalar loop over groups of V arcs (the vector it loads at :122 is never used) --
+ * but it is NOT the same loop as the scalar one: on a block-boundary hit it RETURNS idx + 1 (:143-148) into ProcessArcRange, which
+ * falls through into `for (; e < end; e++)` (:80) with cnt == 0.  `--cnt == 0` (:98) is then never true again, so the scan runs on to
+ * `end`, keeps lowering min, and ProcessArcRange returns `end` (:109).  Only a hit in the scalar tail behind the last full group of V
+ * arcs (or a range shorter than 2 V, :74) stops at the block boundary and returns e + 1 (:98-103). */
+static int opt_range_raw(const int8_t *state, const int64_t *cost, const int32_t *src, const int32_t *tgt, const int64_t *pi,
+                         int start, int end, int block_size, int V, int64_t *min, int *cnt, int *best)
 {
-    int e;
-    for (e = start; e < end; e++) {
-        int64_t c = rc(o, e);
+    int e = start;
+    if (V > 0 && end - start >= V * 2) {                                  /* BSPO.cs:74 */
+        for (; e <= end - V; e += V) {                                    /* BSPO.cs:119 */
+            for (int i = 0; i < V; i++) {                                 /* BSPO.cs:125 */
+                int idx = e + i;
+                int64_t c = (int64_t)state[idx] * (cost[idx] + pi[src[idx]] - pi[tgt[idx]]);
+                if (c < *min) { *min = c; *best = idx; }
+                if (--*cnt == 0) {                                        /* BSPO.cs:143-151 */
+                    if (*min < 0) { e = idx + 1; goto simd_returned; }    /* return idx + 1 */
+                    *cnt = block_size;
+                }
+            }
+        }
+simd_returned: ;
+    }
+    for (; e < end; e++) {                                                /* BSPO.cs:80-107, cnt as the SIMD part left it */
+        int64_t c = (int64_t)state[e] * (cost[e] + pi[src[e]] - pi[tgt[e]]);
         if (c < *min) { *min = c; *best = e; }
-        if (--*cnt == 0) { if (*min < 0) return e + 1; *cnt = o->block_size; }
+        if (--*cnt == 0) { if (*min < 0) return e + 1; *cnt = block_size; }
     }
     return e;
 }
 
-/* BSPO.cs:39-66: wraps only if the first range ended with min >= 0 (D6); next_arc = e + 1 (D5) */
+/* BSPO.cs:39-66 FindEnteringArc: wraps only if the first range ended with min >= 0 (D6); next_arc = what ProcessArcRange returned (D5) */
+static int block_opt_raw(const int8_t *state, const int64_t *cost, const int32_t *src, const int32_t *tgt, const int64_t *pi,
+                         int m_s, int block_size, int V, int *next_arc, int *in_arc, int64_t *rcost)
+{
+    int64_t min = 0; int cnt = block_size, best = -1, e;
+    e = opt_range_raw(state, cost, src, tgt, pi, *next_arc, m_s, block_size, V, &min, &cnt, &best);
+    if (e >= m_s && min >= 0)
+        e = opt_range_raw(state, cost, src, tgt, pi, 0, *next_arc, block_size, V, &min, &cnt, &best);
+    if (min >= 0) return 0;
+    *next_arc = e; *in_arc = best; if (rcost) *rcost = min;
+    return 1;
+}
+
 static int find_block_opt(ns_oracle *o)
 {
-    int64_t min = 0; int cnt = o->block_size, best = -1, e;
-    e = opt_range(o, o->next_arc, o->search_arc_num, &min, &cnt, &best);
-    if (e >= o->search_arc_num && min >= 0)
-        e = opt_range(o, 0, o->next_arc, &min, &cnt, &best);
-    if (min >= 0) return 0;
-    o->next_arc = e; o->in_arc = best;
-    return 1;
+    return block_opt_raw(o->state, o->cost, o->src, o->tgt, o->pi, o->search_arc_num, o->block_size, o->vector_width,
+                         &o->next_arc, &o->in_arc, NULL);
 }
 
 static double now_ns(void)
@@ -872,34 +912,25 @@ NSO_API int nso_scan_first(int m_s, const int8_t *state, const int64_t *cost, co
 }
 
 NSO_API int nso_scan_block(int m_s, const int8_t *state, const int64_t *cost, const int32_t *src,
-                           const int32_t *tgt, const int64_t *pi, int block_size, int optimized,
+                           const int32_t *tgt, const int64_t *pi, int block_size, int optimized, int vector_width,
                            int32_t *next_arc, int32_t *arc, int64_t *rcost)
 {
-    int64_t min = 0; int cnt = block_size, e, best = -1;
-    if (!optimized) {
-        for (e = *next_arc; e < m_s; e++) {
-            int64_t c = RC(e); if (c < min) { min = c; best = e; }
-            if (--cnt == 0) { if (min < 0) goto hit; cnt = block_size; }
-        }
-        for (e = 0; e < *next_arc; e++) {
-            int64_t c = RC(e); if (c < min) { min = c; best = e; }
-            if (--cnt == 0) { if (min < 0) goto hit; cnt = block_size; }
-        }
-        if (min >= 0) return 0;
-    } else {
-        int hit = 0;
-        for (e = *next_arc; e < m_s; e++) {
-            int64_t c = RC(e); if (c < min) { min = c; best = e; }
-            if (--cnt == 0) { if (min < 0) { e = e + 1; hit = 1; break; } cnt = block_size; }
-        }
-        if (!hit && e >= m_s && min >= 0) {
-            for (e = 0; e < *next_arc; e++) {
-                int64_t c = RC(e); if (c < min) { min = c; best = e; }
-                if (--cnt == 0) { if (min < 0) { e = e + 1; break; } cnt = block_size; }
-            }
-        }
-        if (min >= 0) return 0;
+    if (optimized) {
+        int na = *next_arc, a = -1;
+        const int f = block_opt_raw(state, cost, src, tgt, pi, m_s, block_size, vector_width, &na, &a, rcost);
+        if (f) { *next_arc = na; *arc = a; }
+        return f;
     }
+    int64_t min = 0; int cnt = block_size, e, best = -1;
+    for (e = *next_arc; e < m_s; e++) {
+        int64_t c = RC(e); if (c < min) { min = c; best = e; }
+        if (--cnt == 0) { if (min < 0) goto hit; cnt = block_size; }
+    }
+    for (e = 0; e < *next_arc; e++) {
+        int64_t c = RC(e); if (c < min) { min = c; best = e; }
+        if (--cnt == 0) { if (min < 0) goto hit; cnt = block_size; }
+    }
+    if (min >= 0) return 0;
 hit:
     *next_arc = e; *arc = best; if (rcost) *rcost = min;
     return 1;

@@ -54,6 +54,7 @@ def lib():
     L.nso_run_pivots.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.nso_set_config.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]
     L.nso_set_auto_config.argtypes = [C.c_void_p, C.c_int]
+    L.nso_set_vector_width.argtypes = [C.c_void_p, C.c_int]
     L.nso_enable_timing.argtypes = [C.c_void_p, C.c_int]
     L.nso_phase_us.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     for f in ("nso_status", "nso_search_arc_num", "nso_all_arc_num", "nso_block_size", "nso_next_arc",
@@ -75,7 +76,7 @@ def lib():
                                 C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     L.nso_scan_first.argtypes = [C.c_int, _i8p, _i64p, _i32p, _i32p, _i64p,
                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
-    L.nso_scan_block.argtypes = [C.c_int, _i8p, _i64p, _i32p, _i32p, _i64p, C.c_int, C.c_int,
+    L.nso_scan_block.argtypes = [C.c_int, _i8p, _i64p, _i32p, _i32p, _i64p, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     _lib = L
     return L
@@ -107,14 +108,18 @@ class Oracle:
     """One network-simplex run of the CPU restatement."""
 
     def __init__(self, p: Problem, semantics=SEM_CSHARP, rule=RULE_BLOCK, supply_type=GEQ,
-                 arc_mixing=True, block_size=0, auto_config=False, config=None):
-        """auto_config: the reference's SetAutoConfiguration (its default is ON; the oracle's default is OFF so that the
+                 arc_mixing=True, block_size=0, auto_config=False, config=None, vector_width=4):
+        """vector_width: Vector<long>.Count of the machine the reference runs on (BlockSearchPivotOptimized.cs:74, :115): 4 on x64,
+        2 on NEON, 0 = Vector.IsHardwareAccelerated is false.  Only SEM_CSHARP_OPT + RULE_BLOCK reads it.
+        auto_config: the reference's SetAutoConfiguration (its default is ON; the oracle's default is OFF so that the
         plain rule runs with `new OptimizationConfig()`).  config: dict of OptimizationConfig fields (SetOptimizationConfig)."""
         self.p = p
         self.L = lib()
         self.h = self.L.nso_create(p.n, p.m, p.src, p.tgt, p.lower, p.upper, p.cost, p.supply,
                                    semantics, rule, supply_type, int(arc_mixing), block_size)
         self.semantics, self.rule = semantics, rule
+        if not self.L.nso_set_vector_width(self.h, int(vector_width)):
+            raise ValueError(f"vector_width {vector_width} is not one of 0, 2, 4, 8")
         if config is not None:
             c = dict(flags=0, min_block_size=25, max_block_size=100, consecutive_hits_before_adapt=3, min_block_size_ratio=0.125,
                      block_size_growth_factor=1.2, block_size_shrink_factor=0.8, low_hit_rate_threshold=0.05, high_hit_rate_threshold=0.3)
@@ -245,8 +250,8 @@ def scan_first(m_s, state, cost, src, tgt, pi, next_arc):
     return bool(f), a.value, c.value, na.value
 
 
-def scan_block(m_s, state, cost, src, tgt, pi, block_size, optimized, next_arc):
+def scan_block(m_s, state, cost, src, tgt, pi, block_size, optimized, next_arc, vector_width=4):
     a, c, na = C.c_int32(-1), C.c_int64(0), C.c_int32(next_arc)
-    f = lib().nso_scan_block(m_s, *_prep(state, cost, src, tgt, pi), block_size, int(optimized),
+    f = lib().nso_scan_block(m_s, *_prep(state, cost, src, tgt, pi), block_size, int(optimized), int(vector_width),
                              C.byref(na), C.byref(a), C.byref(c))
     return bool(f), a.value, c.value, na.value
