@@ -56,6 +56,15 @@ typedef enum mcf_pivot_rule { MCF_RULE_FIRST_ELIGIBLE = 0, MCF_RULE_BEST_ELIGIBL
 /* Which of the reference's two implementations of a rule is reproduced:
  * PLAIN = the nested classes of NS.cs:1292-1668; OPTIMIZED = BSPO.cs (EnableOptimizedPivot(true)). */
 typedef enum mcf_semantics { MCF_SEM_PLAIN = 1, MCF_SEM_OPTIMIZED = 2 } mcf_semantics;
+/* OPTIMIZED Block Search depends on a property of the MACHINE the reference runs on (difference D14):
+ * BSPO.cs:74 sends ranges of at least 2 * Vector<long>.Count arcs through ProcessArcRangeSIMD when Vector.IsHardwareAccelerated, and a
+ * block-boundary hit in there returns into a scalar loop whose counter is 0 and never reaches 0 again (BSPO.cs:84-99, :143-148): the scan
+ * runs on to the end of the range, the entering arc is the best of the whole range and _nextArc becomes the range's end.  Only a hit in
+ * the tail behind the last full group of Vector<long>.Count arcs stops at the block boundary.  vector_width = Vector<long>.Count:
+ * 4 on x64 (AVX2; also .NET 8 on AVX-512 hardware), 2 on Arm NEON, 8 with 512-bit Vector<T> enabled; MCF_VECTOR_NONE = not hardware
+ * accelerated (the scalar loop alone: stop at the first block boundary behind an eligible arc).  0 = MCF_VECTOR_DEFAULT = 4. */
+#define MCF_VECTOR_DEFAULT 0
+#define MCF_VECTOR_NONE (-1)
 /* Types/SupplyType.cs */
 typedef enum mcf_supply_type { MCF_SUPPLY_GEQ = 0, MCF_SUPPLY_LEQ = 1 } mcf_supply_type;
 /* Types/SolverStatus.cs:7-34 (values kept) */
@@ -99,6 +108,8 @@ typedef struct mcf_engine_desc {
     int32_t resident_workgroups;  /* 0 = auto (one workgroup per CU, at most 256); otherwise a cap on the resident grid: engines that share
                                      a device (arc shards rehearsed on one GPU) must all be co-resident to answer.  Workgroups are dealt
                                      to the 8 XCDs round-robin, so give k engines 8 * (32 / k) each, not 256 / k */
+    int32_t vector_width;         /* MCF_SEM_OPTIMIZED + Block Search: Vector<long>.Count of the reference's host -- 2, 4, 8,
+                                     MCF_VECTOR_NONE, or 0 = 4 (x64).  Ignored by every other rule / flavour */
 } mcf_engine_desc;
 
 #define MCF_ENGINE_SAMPLE_KERNEL_TIME 1   /* time every 16th scan dispatch with HIP events */
@@ -210,11 +221,17 @@ MCF_API int mcf_engine_find_entering(mcf_engine *e, int32_t *found, int32_t *arc
 MCF_API int mcf_engine_search_begin(mcf_engine *e);
 MCF_API int mcf_engine_search_end(mcf_engine *e, int32_t *found, int32_t *arc, int64_t *reduced_cost);
 
-/* Sharded search: the local candidate of this engine's shard, as an exchangeable 16-byte record. */
+/* Sharded search: the local candidate of this engine's shard, as an exchangeable 32-byte record. */
 typedef struct mcf_candidate {
     int64_t reduced_cost;   /* 0 when none */
     uint32_t pos;           /* scan position (rule dependent ordering key); 0xFFFFFFFF when none */
     int32_t arc;            /* -1 when none */
+    /* OPTIMIZED Block Search only (0 / 0xFFFFFFFF / -1 otherwise): the shard's best arc of the first of the reference's two ranges
+     * ([next_arc, m_s), then [0, next_arc)) in which the shard has an eligible arc at all -- what enters when the reference's scan
+     * runs to the end of the range (vector_width above) */
+    int64_t range_cost;
+    uint32_t range_pos;
+    int32_t range_arc;
 } mcf_candidate;
 MCF_API int mcf_engine_find_entering_local(mcf_engine *e, mcf_candidate *out);
 /* second half of a search posted with mcf_engine_search_begin on a sharded engine (the first half is the same call for every engine) */
@@ -225,7 +242,7 @@ MCF_API int mcf_engine_resolve(mcf_engine *e, int32_t count, const mcf_candidate
                                int32_t *arc, int64_t *reduced_cost);
 /* The same MINLOC + next_arc bookkeeping without an engine (stateless; *next_arc is read and advanced): what every rank
  * does with the all-gathered records.  block_size 0 = the reference default for the semantics. */
-MCF_API int mcf_resolve_candidates(int32_t rule, int32_t semantics, int32_t search_arc_num, int32_t block_size, int32_t *next_arc,
+MCF_API int mcf_resolve_candidates(int32_t rule, int32_t semantics, int32_t vector_width, int32_t search_arc_num, int32_t block_size, int32_t *next_arc,
                                    int32_t count, const mcf_candidate *all, int32_t *found, int32_t *arc, int64_t *reduced_cost);
 /* contiguous shard of [0, search_arc_num) for rank r of R, aligned to 4 arcs */
 MCF_API int mcf_shard_range(int32_t search_arc_num, int32_t rank, int32_t world, int32_t *begin, int32_t *end);
@@ -291,7 +308,7 @@ MCF_API int mcf_engine_bench_scan(mcf_engine *e, int32_t reps, int32_t cold, int
  * patches (the candidate cache is bypassed by nothing here: an engine with the cache answers from it).  avg/min in ns. */
 MCF_API int mcf_engine_bench_search(mcf_engine *e, int32_t reps, double *avg_ns, double *min_ns);
 
-/* RCCL exchange for sharded engines: one ncclAllGather of 16 bytes per rank per pivot on the engine's stream.
+/* RCCL exchange for sharded engines: one ncclAllGather of 32 bytes per rank per pivot on the engine's stream.
  * id_out/id: the 128-byte ncclUniqueId, created on rank 0 and broadcast by the caller (torch.distributed). */
 MCF_API int mcf_comm_unique_id(uint8_t id_out[128]);
 MCF_API int mcf_engine_comm_init(mcf_engine *e, const uint8_t id[128], int32_t rank, int32_t world);
@@ -299,8 +316,8 @@ MCF_API int mcf_engine_comm_init(mcf_engine *e, const uint8_t id[128], int32_t r
 MCF_API int mcf_engine_find_entering_sharded(mcf_engine *e, int32_t *found, int32_t *arc, int64_t *reduced_cost);
 
 /* Host exchange for sharded engines ("per-GPU result slots reduced by the host"): the ranks of ONE node put their
- * 16-byte candidates into POSIX shared memory and read each other's -- an all-gather without a collective library, a fraction of a
- * microsecond per pivot where one ncclAllGather of 16 bytes costs tens.  name: the same on every rank, "/something" (shm_open);
+ * 32-byte candidates into POSIX shared memory and read each other's -- an all-gather without a collective library, a fraction of a
+ * microsecond per pivot where one ncclAllGather of 32 bytes costs tens.  name: the same on every rank, "/something" (shm_open);
  * all ranks must have returned from mcf_exchange_open (any barrier of the caller's) before the first mcf_exchange_all_gather. */
 typedef struct mcf_exchange mcf_exchange;
 MCF_API int mcf_exchange_open(mcf_exchange **out, const char *name, int32_t rank, int32_t world);
@@ -324,6 +341,9 @@ MCF_API int mcf_ns_set_problem(mcf_ns *s, const int64_t *lower, const int64_t *u
 MCF_API int mcf_ns_set_supply_type(mcf_ns *s, int32_t type);                               /* NS.cs:197-201 */
 MCF_API int mcf_ns_set_pivot_rule(mcf_ns *s, int32_t rule);                                /* NS.cs:206-210 */
 MCF_API int mcf_ns_enable_optimized_pivot(mcf_ns *s, int32_t enable);                      /* NS.cs:532-535 */
+/* Vector<long>.Count of the machine whose EnableOptimizedPivot(true) Block Search is reproduced (mcf_engine_desc.vector_width; the
+ * reference has no setter, it reads the property: BSPO.cs:74, :115).  Default 4 = x64. */
+MCF_API int mcf_ns_set_vector_width(mcf_ns *s, int32_t vector_width);
 /* SetOptimizationConfig (NS.cs:557-561; switches auto-configuration off), EnableOptimizations (NS.cs:549-552),
  * SetAutoConfiguration (NS.cs:567-570; the reference's default is ON, and so is this library's) */
 MCF_API int mcf_ns_set_optimization_config(mcf_ns *s, const mcf_block_config *config);

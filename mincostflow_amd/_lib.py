@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmcf_hip.so")
 # enums of include/mcf_hip.h
 RULE_FIRST_ELIGIBLE, RULE_BEST_ELIGIBLE, RULE_BLOCK_SEARCH = 0, 1, 2
 SEM_PLAIN, SEM_OPTIMIZED = 1, 2
+VECTOR_DEFAULT, VECTOR_NONE = 0, -1          # mcf_engine_desc.vector_width: 0 = 4 (x64), -1 = Vector.IsHardwareAccelerated is false
 SUPPLY_GEQ, SUPPLY_LEQ = 0, 1
 NOT_SOLVED, OPTIMAL, INFEASIBLE, UNBOUNDED, UNBALANCED = 0, 1, 2, 3, 4
 STATE_UPPER, STATE_TREE, STATE_LOWER = -1, 0, 1
@@ -34,11 +35,15 @@ class McfError(RuntimeError):
 
 class EngineDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("node_count", "arc_capacity", "search_arc_num", "int_width", "rule", "semantics",
-                                         "block_size", "device", "shard_begin", "shard_end", "scan_workgroups", "flags", "resident_workgroups")]
+                                         "block_size", "device", "shard_begin", "shard_end", "scan_workgroups", "flags", "resident_workgroups", "vector_width")]
 
 
 class Candidate(C.Structure):
-    _fields_ = [("reduced_cost", C.c_int64), ("pos", C.c_uint32), ("arc", C.c_int32)]
+    _fields_ = [("reduced_cost", C.c_int64), ("pos", C.c_uint32), ("arc", C.c_int32),
+                ("range_cost", C.c_int64), ("range_pos", C.c_uint32), ("range_arc", C.c_int32)]
+
+    def __init__(self, reduced_cost=0, pos=0xFFFFFFFF, arc=-1, range_cost=0, range_pos=0xFFFFFFFF, range_arc=-1):
+        super().__init__(reduced_cost, pos, arc, range_cost, range_pos, range_arc)
 
 
 class EngineStats(C.Structure):
@@ -136,7 +141,7 @@ SIGNATURES = {
     "mcf_exchange_close": (None, [C.c_void_p]),
     "mcf_exchange_all_gather": (C.c_int, [C.c_void_p, _P(Candidate), _P(Candidate)]),
     "mcf_engine_resolve": (C.c_int, [C.c_void_p, C.c_int32, _P(Candidate), _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
-    "mcf_resolve_candidates": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), C.c_int32, _P(Candidate),
+    "mcf_resolve_candidates": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), C.c_int32, _P(Candidate),
                                         _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
     "mcf_shard_range": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
     "mcf_engine_park": (C.c_int, [C.c_void_p]),
@@ -166,6 +171,7 @@ SIGNATURES = {
     "mcf_ns_set_supply_type": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_ns_set_pivot_rule": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_ns_enable_optimized_pivot": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mcf_ns_set_vector_width": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_ns_set_optimization_config": (C.c_int, [C.c_void_p, _P(BlockConfig)]),
     "mcf_ns_enable_optimizations": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_ns_set_auto_configuration": (C.c_int, [C.c_void_p, C.c_int32]),

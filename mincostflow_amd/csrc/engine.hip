@@ -164,6 +164,8 @@ struct mcf_engine {
     // a search that has been posted / launched but not collected yet (mcf_engine_search_begin .. _end)
     enum { kNoSearch = 0, kAnswered, kResidentSearch, kCandSearch, kDispatchSearch } in_flight = kNoSearch;
     Key answered{0, kNone, kNone};
+    Key range_key{0, kNone, kNone};   // OPTIMIZED Block Search: the range key of the search collected last (kernels.hip.h: kDual)
+    int vec = 0;                      // Vector<long>.Count of the reference's host for that rule (0 = not hardware accelerated): desc.vector_width
     bool in_flight_timed = false;
     int stream_lines = 0;          // entry lines of the coming request that an "apply" post has already put in place
     uint32_t stream_sub = 0;       // counter of those posts
@@ -695,7 +697,9 @@ int local_search(mcf_engine *e, Key *k)
 
 // entering arc, reduced cost and the rule's next_arc from the winning key (host part of the rules)
 // *checked (optional) = arcs the reference's plain BlockSearchPivot examines in this call (its arcsChecked, NS.cs:1345-1372); 0 for the others
-void resolve_key_raw(int rule, int semantics, int m_s, int B, int &next_arc, const Key &k, int32_t *found, int32_t *arc, int64_t *rcost, int64_t *checked = nullptr)
+// vec / range: OPTIMIZED Block Search on a host with Vector<long>.Count == vec (0: not hardware accelerated); range = the scan's range key
+void resolve_key_raw(int rule, int semantics, int vec, int m_s, int B, int &next_arc, const Key &k, const Key &range, int32_t *found, int32_t *arc, int64_t *rcost,
+                     int64_t *checked = nullptr)
 {
     const bool counts = rule == MCF_RULE_BLOCK_SEARCH && semantics != MCF_SEM_OPTIMIZED;
     if (checked) *checked = counts ? m_s : 0;         // nothing eligible, or the cycle ran out before a block boundary: every arc once
@@ -713,20 +717,38 @@ void resolve_key_raw(int rule, int semantics, int m_s, int B, int &next_arc, con
         if (boundary <= m_s - 1) { next_arc = (int)((boundary + na) % m_s); if (checked) *checked = boundary + 1; }
         return;
     }
-    // BSPO.cs:49-63,98-103: first range [next_arc, m_s), wrapped range [0, next_arc) only if nothing was found
+    // BSPO.cs:49-63: first range [next_arc, m_s), wrapped range [0, next_arc) only if the first one found nothing.  The counter runs on
+    // across the two (ref cnt), so the first block boundary behind an eligible arc is the one the block key names.  Where that boundary
+    // falls decides what the reference does there (BSPO.cs:69-156):
+    //   * inside the "SIMD" part of its range -- the first floor(len / vec) * vec arcs of a range of len >= 2 * vec arcs, vec > 0 --
+    //     ProcessArcRangeSIMD returns idx + 1 and ProcessArcRange's scalar loop carries on with cnt == 0, which never counts down to 0
+    //     again: it scans to the END of the range, min / bestArc end up as the best arc of the whole range (strict <: first in scan
+    //     order among equals; the blocks before the hit held nothing eligible), and the range's end is returned -> _nextArc;
+    //   * in the scalar tail, or in a range too short for the SIMD part, or with vec == 0: stop there, _nextArc = boundary arc + 1;
+    //   * behind the end of the range (a partial last block): the range ends first and ProcessArcRange returns `end`.
     const int64_t len1 = next_arc >= m_s ? 0 : m_s - next_arc;
-    if (a >= next_arc && next_arc < m_s) {
-        next_arc = boundary < len1 ? (int)(next_arc + boundary + 1) : m_s;
+    const bool first_range = a >= next_arc && next_arc < m_s;
+    const int64_t start = first_range ? 0 : len1;                    // scan position where the winning arc's range begins ...
+    const int64_t len = first_range ? len1 : m_s - len1;             // ... and its length
+    const int range_end = first_range ? m_s : next_arc;              // what ProcessArcRange returns when it runs to `end`
+    if (boundary < start + len) {
+        const bool simd_hit = vec > 0 && len >= 2 * (int64_t)vec && boundary - start < len / vec * vec;
+        if (simd_hit) {
+            *arc = (int)(((int64_t)range.p + na) % m_s);             // the range key: the first range with an eligible arc is this one
+            if (rcost) *rcost = range.c;
+            next_arc = range_end;
+        } else {
+            next_arc = (int)(first_range ? next_arc + boundary + 1 : boundary - len1 + 1);
+        }
     } else {
-        if (boundary < m_s) next_arc = (int)(boundary - len1 + 1);
-        /* else: the range ended first, ProcessArcRange returns `end` = the old next_arc */
+        next_arc = range_end;                                        // first range: m_s (BSPO.cs:52 does not wrap, min < 0); wrapped: unchanged
     }
 }
 
 void resolve_key(mcf_engine *e, const Key &k, int32_t *found, int32_t *arc, int64_t *rcost)
 {
     int64_t checked = 0;
-    resolve_key_raw(e->d.rule, e->d.semantics, e->d.search_arc_num, e->block_size, e->next_arc, k, found, arc, rcost, &checked);
+    resolve_key_raw(e->d.rule, e->d.semantics, e->vec, e->d.search_arc_num, e->block_size, e->next_arc, k, e->range_key, found, arc, rcost, &checked);
     e->st.arcs_checked += checked;
     if (!*found || !e->cfg_set || !(e->cfg.flags & MCF_OPT_ADAPTIVE_BLOCK_SIZE) || e->d.rule != MCF_RULE_BLOCK_SEARCH || e->d.semantics == MCF_SEM_OPTIMIZED) return;
     int32_t counters[2] = {e->low_hits, e->high_hits};
@@ -736,8 +758,8 @@ void resolve_key(mcf_engine *e, const Key &k, int32_t *found, int32_t *arc, int6
     if (e->block_size < 1) e->block_size = 1;       // a block of 0 arcs never reaches a boundary in the reference; keep the kernels' divisor sane
 }
 
-// MINLOC over the shards' candidates with the rule's ordering
-Key merge_candidates(int rule, int semantics, int m_s, int B, int next_arc, int count, const mcf_candidate *all)
+// MINLOC over the shards' candidates with the rule's ordering; *range_out = the same over their range keys (OPTIMIZED Block Search)
+Key merge_candidates(int rule, int semantics, int m_s, int B, int next_arc, int count, const mcf_candidate *all, Key *range_out)
 {
     const bool block_rule = rule == MCF_RULE_BLOCK_SEARCH, best_rule = rule == MCF_RULE_BEST_ELIGIBLE;
     int rstar = -1;
@@ -745,7 +767,7 @@ Key merge_candidates(int rule, int semantics, int m_s, int B, int next_arc, int 
         const int len1 = m_s - next_arc;
         if (len1 % B) rstar = len1 / B;
     }
-    Key best{0, kNone, kNone};
+    Key best{0, kNone, kNone}, range{0, kNone, kNone};
     for (int i = 0; i < count; ++i) {
         if (all[i].pos == kNone) continue;
         Key k{all[i].reduced_cost, 0, all[i].pos};
@@ -758,7 +780,12 @@ Key merge_candidates(int rule, int semantics, int m_s, int B, int next_arc, int 
             take = best.p == kNone || k.r < best.r || (k.r == best.r && (k.c < best.c || (k.c == best.c && k.p < best.p)));
         }
         if (take) best = k;
+        if (block_rule && semantics == MCF_SEM_OPTIMIZED && all[i].range_pos != kNone) {
+            Key q{all[i].range_cost, (next_arc < m_s && all[i].range_arc < next_arc) ? 1u : 0u, all[i].range_pos};
+            if (range.p == kNone || q.r < range.r || (q.r == range.r && (q.c < range.c || (q.c == range.c && q.p < range.p)))) range = q;
+        }
     }
+    if (range_out) *range_out = range;
     return best;
 }
 
@@ -792,6 +819,8 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
     if (desc->int_width != 32 && desc->int_width != 64) return mcf::fail(MCF_ERR_INVALID, "int_width must be 32 or 64");
     if (desc->rule < 0 || desc->rule > 2) return mcf::fail(MCF_ERR_INVALID, "pivot rule %d not implemented (NS.cs:884)", desc->rule);
     if (desc->semantics != MCF_SEM_PLAIN && desc->semantics != MCF_SEM_OPTIMIZED) return mcf::fail(MCF_ERR_INVALID, "bad semantics %d", desc->semantics);
+    if (desc->vector_width != MCF_VECTOR_DEFAULT && desc->vector_width != MCF_VECTOR_NONE && desc->vector_width != 2 && desc->vector_width != 4 && desc->vector_width != 8)
+        return mcf::fail(MCF_ERR_INVALID, "vector_width %d is not Vector<long>.Count of any machine (2, 4, 8, MCF_VECTOR_NONE, or 0 = 4)", desc->vector_width);
     if (mcf_device_count() <= desc->device || desc->device < 0)
         return mcf::fail(MCF_ERR_NO_DEVICE, "HIP device %d not available (%d visible); this library has no CPU search path", desc->device, mcf_device_count());
     HIP_TRY(hipSetDevice(desc->device));
@@ -799,6 +828,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
     e->cal_ns = mcf::now_ns();
     e->cal_ticks = (double)__rdtsc();
     e->d = *desc;
+    e->vec = desc->vector_width == MCF_VECTOR_NONE ? 0 : (desc->vector_width == MCF_VECTOR_DEFAULT ? 4 : desc->vector_width);
     e->begin = desc->shard_begin;
     e->end = desc->shard_end;
     if (e->begin == 0 && e->end == 0) e->end = desc->search_arc_num;
@@ -851,7 +881,6 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
     {
         bool want = !e->resident_reg && !e->lds_pi;
         if (const char *u = getenv("MCF_HIP_RC")) want = u[0] == '1' ? true : (u[0] == '0' ? false : want);
-        if (desc->flags & (MCF_ENGINE_NO_INLINE_UPDATE)) want = want && true;
         e->rc_mode = want;
         if (e->rc_mode) {
             // pure streaming: more bytes in flight per thread, the grid sized so that every workgroup gets the same number of trips
@@ -921,7 +950,6 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         bool rc_resident = e->rc_mode && (desc->flags & MCF_ENGINE_DISPATCH) == 0 && !(getenv("MCF_HIP_RC_RESIDENT") && getenv("MCF_HIP_RC_RESIDENT")[0] == '0');
         if (e->rc_mode) want = rc_resident;
         if (env && env[0] == '1' && !e->rc_mode) want = true;
-        (void)rc_resident;
         if (env && env[0] == '0') want = false;
         // an arc shard is served by a resident grid like a whole instance (every workgroup applies every potential patch, state patches
         // outside the shard are ignored); only the RCCL exchange needs the stream, and mcf_engine_comm_init switches to dispatch mode
@@ -1428,9 +1456,14 @@ void key_to_candidate(const mcf_engine *e, const Key &k, mcf_candidate *out)
 {
     out->reduced_cost = k.p == kNone ? 0 : k.c;
     out->pos = k.p;
+    const int na = e->next_arc >= e->d.search_arc_num ? 0 : e->next_arc;
     if (k.p == kNone) out->arc = -1;
     else if (e->d.rule == MCF_RULE_BEST_ELIGIBLE) out->arc = (int32_t)k.p;
-    else { const int na = e->next_arc >= e->d.search_arc_num ? 0 : e->next_arc; out->arc = (int32_t)(((int64_t)k.p + na) % e->d.search_arc_num); }
+    else out->arc = (int32_t)(((int64_t)k.p + na) % e->d.search_arc_num);
+    const bool dual = e->d.rule == MCF_RULE_BLOCK_SEARCH && e->d.semantics == MCF_SEM_OPTIMIZED && e->range_key.p != kNone;
+    out->range_cost = dual ? e->range_key.c : 0;
+    out->range_pos = dual ? e->range_key.p : kNone;
+    out->range_arc = dual ? (int32_t)(((int64_t)e->range_key.p + na) % e->d.search_arc_num) : -1;
 }
 }  // namespace
 
@@ -1457,21 +1490,24 @@ int mcf_engine_find_entering_local(mcf_engine *e, mcf_candidate *out)
 int mcf_engine_resolve(mcf_engine *e, int32_t count, const mcf_candidate *all, int32_t *found, int32_t *arc, int64_t *reduced_cost)
 {
     if (!e || count < 0 || (count && !all) || !found || !arc) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_resolve: bad arguments");
-    const Key best = merge_candidates(e->d.rule, e->d.semantics, e->d.search_arc_num, e->block_size, e->next_arc, count, all);
+    const Key best = merge_candidates(e->d.rule, e->d.semantics, e->d.search_arc_num, e->block_size, e->next_arc, count, all, &e->range_key);
     resolve_key(e, best, found, arc, reduced_cost);
     return MCF_OK;
 }
 
-int mcf_resolve_candidates(int32_t rule, int32_t semantics, int32_t search_arc_num, int32_t block_size, int32_t *next_arc,
+int mcf_resolve_candidates(int32_t rule, int32_t semantics, int32_t vector_width, int32_t search_arc_num, int32_t block_size, int32_t *next_arc,
                            int32_t count, const mcf_candidate *all, int32_t *found, int32_t *arc, int64_t *reduced_cost)
 {
     if (!next_arc || count < 0 || (count && !all) || !found || !arc || rule < 0 || rule > 2 || search_arc_num < 0 ||
-        (semantics != MCF_SEM_PLAIN && semantics != MCF_SEM_OPTIMIZED) || *next_arc < 0 || *next_arc > search_arc_num)
+        (semantics != MCF_SEM_PLAIN && semantics != MCF_SEM_OPTIMIZED) || *next_arc < 0 || *next_arc > search_arc_num ||
+        (vector_width != MCF_VECTOR_DEFAULT && vector_width != MCF_VECTOR_NONE && vector_width != 2 && vector_width != 4 && vector_width != 8))
         return mcf::fail(MCF_ERR_INVALID, "mcf_resolve_candidates: bad arguments");
     const int B = block_size > 0 ? block_size : mcf::default_block_size(search_arc_num, semantics);
-    const Key best = merge_candidates(rule, semantics, search_arc_num, B, *next_arc, count, all);
+    const int vec = vector_width == MCF_VECTOR_NONE ? 0 : (vector_width == MCF_VECTOR_DEFAULT ? 4 : vector_width);
+    Key range{0, kNone, kNone};
+    const Key best = merge_candidates(rule, semantics, search_arc_num, B, *next_arc, count, all, &range);
     int na = *next_arc;
-    resolve_key_raw(rule, semantics, search_arc_num, B, na, best, found, arc, reduced_cost);
+    resolve_key_raw(rule, semantics, vec, search_arc_num, B, na, best, range, found, arc, reduced_cost);
     *next_arc = na;
     return MCF_OK;
 }
@@ -1722,14 +1758,15 @@ int mcf_engine_find_entering_sharded(mcf_engine *e, int32_t *found, int32_t *arc
             if (len1 % e->block_size) rstar = len1 / e->block_size;
         }
         const dim3 one(1), block(kThreads);
+        const int dual = e->d.rule == MCF_RULE_BLOCK_SEARCH && e->d.semantics == MCF_SEM_OPTIMIZED ? 1 : 0;
         switch (e->d.rule) {
-        case MCF_RULE_BEST_ELIGIBLE: hipLaunchKernelGGL(reduce_records_kernel<MCF_RULE_BEST_ELIGIBLE>, one, block, 0, e->stream, e->d_dev_slots, e->grid, e->d.search_arc_num, na, e->next_arc, e->block_size, rstar, e->d_cand_local); break;
-        case MCF_RULE_FIRST_ELIGIBLE: hipLaunchKernelGGL(reduce_records_kernel<MCF_RULE_FIRST_ELIGIBLE>, one, block, 0, e->stream, e->d_dev_slots, e->grid, e->d.search_arc_num, na, e->next_arc, e->block_size, rstar, e->d_cand_local); break;
-        default: hipLaunchKernelGGL(reduce_records_kernel<MCF_RULE_BLOCK_SEARCH>, one, block, 0, e->stream, e->d_dev_slots, e->grid, e->d.search_arc_num, na, e->next_arc, e->block_size, rstar, e->d_cand_local);
+        case MCF_RULE_BEST_ELIGIBLE: hipLaunchKernelGGL(reduce_records_kernel<MCF_RULE_BEST_ELIGIBLE>, one, block, 0, e->stream, e->d_dev_slots, e->grid, e->d.search_arc_num, na, e->next_arc, e->block_size, rstar, dual, e->d_cand_local); break;
+        case MCF_RULE_FIRST_ELIGIBLE: hipLaunchKernelGGL(reduce_records_kernel<MCF_RULE_FIRST_ELIGIBLE>, one, block, 0, e->stream, e->d_dev_slots, e->grid, e->d.search_arc_num, na, e->next_arc, e->block_size, rstar, dual, e->d_cand_local); break;
+        default: hipLaunchKernelGGL(reduce_records_kernel<MCF_RULE_BLOCK_SEARCH>, one, block, 0, e->stream, e->d_dev_slots, e->grid, e->d.search_arc_num, na, e->next_arc, e->block_size, rstar, dual, e->d_cand_local);
         }
         HIP_TRY(hipGetLastError());
     }
-    // MINLOC over (key, arc): RCCL has no MINLOC, so all-gather the 16-byte records and reduce locally
+    // MINLOC over (key, arc): RCCL has no MINLOC, so all-gather the 32-byte records and reduce locally
     const int nrc = rccl()->all_gather(e->d_cand_local, e->d_cand_all, sizeof(mcf_candidate), kNcclChar, e->comm, e->stream);
     if (nrc != 0) return mcf::fail(MCF_ERR_COMM, "ncclAllGather: %s", rccl()->error_string ? rccl()->error_string(nrc) : "error");
     HIP_TRY(hipMemcpyAsync(e->h_cand_all, e->d_cand_all, sizeof(mcf_candidate) * e->world, hipMemcpyDeviceToHost, e->stream));

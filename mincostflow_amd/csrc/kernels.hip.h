@@ -53,6 +53,12 @@ struct Key {
     uint32_t r;   // Block Search: rank of the block in scan order (doubled, +1 for the wrapped half in OPTIMIZED)
     uint32_t p;   // Best: arc index; First/Block: position in the cyclic scan that starts at next_arc
 };
+// OPTIMIZED Block Search answers with TWO keys (kDual): the block key above and the RANGE key (r = 0 for arcs of the first range
+// [next_arc, m_s), 1 for the wrapped range [0, next_arc); then c, then the scan position) = the best arc of the first range that holds
+// an eligible arc at all.  On a host with Vector.IsHardwareAccelerated the reference's scan does not stop at the block boundary when the
+// hit falls into the "SIMD" part of the range (BSPO.cs:84-99 falls through with cnt == 0 and runs to the end of the range): the entering
+// arc is then the range key's, and which of the two applies follows from the block key alone (engine.hip: resolve_key_raw).
+template <int RULE, bool OPT> constexpr bool kDual = RULE == MCF_RULE_BLOCK_SEARCH && OPT;
 
 template <typename T>
 struct ScanParams {
@@ -206,7 +212,7 @@ __device__ __forceinline__ void gather_tile(const TileData<T> &d, const T *pi, T
 // order inside a bucket, so only a tie with the running best costs the two look-ups.
 template <typename T, int RULE, bool OPT, bool PERM = false>
 __device__ __forceinline__ void fold_tile(const TileData<T> &d, const T ps[4], const T pt[4], int e0, int m_s, int next_arc, int block_size, int rstar,
-                                          Key &best, const int32_t *orig = nullptr, int base = 0)
+                                          Key &best, Key &range, const int32_t *orig = nullptr, int base = 0)
 {
     uint32_t pos0 = 0;
     if (RULE != MCF_RULE_BEST_ELIGIBLE) {
@@ -231,14 +237,17 @@ __device__ __forceinline__ void fold_tile(const TileData<T> &d, const T ps[4], c
             } else {
                 uint32_t r = pos / (uint32_t)block_size;
                 r = 2 * r + ((OPT && (int)r == rstar && e0 + j < next_arc) ? 1u : 0u);
-                if (rc < 0) take_if_better<RULE>(best, rc, r, pos);
+                if (rc < 0) {
+                    take_if_better<RULE>(best, rc, r, pos);
+                    if (OPT) take_if_better<RULE>(range, rc, e0 + j < next_arc ? 1u : 0u, pos);
+                }
             }
         }
     }
 }
 
 template <typename T, int RULE, bool OPT, bool PERM = false>
-__device__ __forceinline__ void eval_tile(const TileData<T> &d, const T *pi, int e0, int m_s, int next_arc, int block_size, int rstar, Key &best,
+__device__ __forceinline__ void eval_tile(const TileData<T> &d, const T *pi, int e0, int m_s, int next_arc, int block_size, int rstar, Key &best, Key &range,
                                           int sub_node = -1, T sub_val = 0, const int32_t *orig = nullptr, int base = 0)
 {
     T ps[4], pt[4];
@@ -246,25 +255,28 @@ __device__ __forceinline__ void eval_tile(const TileData<T> &d, const T *pi, int
     // a single patched potential whose store may still be in flight (resident fast path): take its value from the request
 #pragma unroll
     for (int j = 0; j < 4; ++j) { ps[j] = d.s.v[j] == sub_node ? sub_val : ps[j]; pt[j] = d.t.v[j] == sub_node ? sub_val : pt[j]; }
-    fold_tile<T, RULE, OPT, PERM>(d, ps, pt, e0, m_s, next_arc, block_size, rstar, best, orig, base);
+    fold_tile<T, RULE, OPT, PERM>(d, ps, pt, e0, m_s, next_arc, block_size, rstar, best, range, orig, base);
 }
 
 template <typename T, int RULE, bool OPT, bool NT = false, bool PERM = false>
-__device__ __forceinline__ void scan_tile(const ScanParams<T> &p, int i0, Key &best)
+__device__ __forceinline__ void scan_tile(const ScanParams<T> &p, int i0, Key &best, Key &range)
 {
     TileData<T> d;
     load_tile<T, NT>(p.src, p.tgt, p.cost, p.state, i0, d);
-    eval_tile<T, RULE, OPT, PERM>(d, p.pi, p.base + i0, p.m_s, p.next_arc, p.block_size, p.rstar, best, -1, (T)0, p.orig, p.base);
+    eval_tile<T, RULE, OPT, PERM>(d, p.pi, p.base + i0, p.m_s, p.next_arc, p.block_size, p.rstar, best, range, -1, (T)0, p.orig, p.base);
 }
 
 // workgroup-level finish: wave butterfly -> LDS -> one 16-byte record.  SYSTEM = write-through store for kernels that keep running.
-template <int RULE, bool SYSTEM, int NT = kThreads>
-__device__ __forceinline__ void publish_best(Key best, Slot *slot, uint32_t tag, bool full_line = false)
+// DUAL (OPTIMIZED Block Search): the range key is folded the same way and fills the second half of the line (records 2 and 3).
+template <int RULE, bool SYSTEM, int NT = kThreads, bool DUAL = false>
+__device__ __forceinline__ void publish_best(Key best, Slot *slot, uint32_t tag, bool full_line = false, Key range = Key{0, kNone, kNone})
 {
     const int tid = threadIdx.x;
     best = wave_min<RULE>(best);
+    if (DUAL) range = wave_min<RULE>(range);
     __shared__ Key wave_best[NT / 64];
-    if ((tid & 63) == 0) wave_best[tid >> 6] = best;
+    __shared__ Key wave_range[DUAL ? NT / 64 : 1];
+    if ((tid & 63) == 0) { wave_best[tid >> 6] = best; if (DUAL) wave_range[tid >> 6] = range; }
     __syncthreads();
     if (tid < 64) {
         // second stage: lane w takes wave w's result (at most 16 waves: one row of lanes), the same four row steps fold them
@@ -281,14 +293,28 @@ __device__ __forceinline__ void publish_best(Key best, Slot *slot, uint32_t tag,
         k.c = lane_i64(k.c, 0);
         k.p = lane_u32(k.p, 0);
         k.r = lane_u32(k.r, 0);
+        if (DUAL) {
+            Key q;
+            q.c = tid < waves ? wave_range[w].c : 0;
+            q.r = tid < waves ? wave_range[w].r : kNone;
+            q.p = tid < waves ? wave_range[w].p : kNone;
+            wave_min_step<RULE, kDppXor1>(q);
+            wave_min_step<RULE, kDppXor2>(q);
+            wave_min_step<RULE, kDppHalfMirror>(q);
+            wave_min_step<RULE, kDppMirror>(q);
+            q.c = lane_i64(q.c, 0);
+            q.p = lane_u32(q.p, 0);
+            if (tid >= 2) { k.c = q.c; k.p = q.p; }        // lanes 2 and 3 carry the range key
+        }
         typedef uint32_t v4u __attribute__((ext_vector_type(4)));
         v4u out;
         out.x = (uint32_t)(uint64_t)k.c;
         out.y = (uint32_t)((uint64_t)k.c >> 32);
         out.z = k.p;
         out.w = record_tag(tag, k.c, k.p);
-        // full_line: lanes 0..3 write the record four times = one whole 64-byte line (no partial-line write on the host side)
-        const int lanes = full_line ? 4 : 1;
+        // full_line: lanes 0..3 write four records = one whole 64-byte line (no partial-line write on the host side): the record four
+        // times, or (DUAL) the block key twice and the range key twice
+        const int lanes = (full_line || DUAL) ? 4 : 1;
         if (tid < lanes) {
             if (SYSTEM) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(slot + tid), "v"(out) : "memory");
             else *reinterpret_cast<v4u *>(slot + tid) = out;
@@ -313,17 +339,14 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(const ScanParams<T> p)
         __syncthreads();
     }
 
-    Key best;
-    best.c = 0;
-    best.r = kNone;
-    best.p = kNone;
+    Key best{0, kNone, kNone}, range{0, kNone, kNone};
     const int step = gridDim.x * kTile * UNROLL;
     for (int i0 = blockIdx.x * kTile * UNROLL + tid * kArcsPerThread; i0 < p.count_padded; i0 += step) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) scan_tile<T, RULE, OPT, NT, PERM>(p, i0 + u * kTile, best);
+        for (int u = 0; u < UNROLL; ++u) scan_tile<T, RULE, OPT, NT, PERM>(p, i0 + u * kTile, best, range);
     }
     if (PERM && best.p != kNone) best.p = (uint32_t)p.orig[(int)best.p - p.base];     // position -> arc id; from here on everything is as without PERM
-    publish_best<RULE, false>(best, p.slots + (size_t)blockIdx.x * kSlotStride, p.seq, true);
+    publish_best<RULE, false, kThreads, kDual<RULE, OPT>>(best, p.slots + (size_t)blockIdx.x * kSlotStride, p.seq, true, range);
 }
 
 // ------------------------------------------------------------------------------------------------ reduced costs kept per arc (RC layout)
@@ -334,7 +357,7 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(const ScanParams<T> p)
 // adds the node's change to d of its out-arcs and subtracts it from d of its in-arcs (integer atomics: exact in any order; an arc inside
 // the moved subtree gets +delta and -delta).  Same reduced costs, bit for bit, same keys, same tie-breaks (arcs keep their own order).
 template <int RULE, bool OPT>
-__device__ __forceinline__ void fold_rc(uint32_t st4, const int64_t d[4], int e0, int m_s, int next_arc, int block_size, int rstar, Key &best)
+__device__ __forceinline__ void fold_rc(uint32_t st4, const int64_t d[4], int e0, int m_s, int next_arc, int block_size, int rstar, Key &best, Key &range)
 {
     uint32_t pos0 = 0;
     if (RULE != MCF_RULE_BEST_ELIGIBLE) {
@@ -356,7 +379,10 @@ __device__ __forceinline__ void fold_rc(uint32_t st4, const int64_t d[4], int e0
             } else {
                 uint32_t r = pos / (uint32_t)block_size;
                 r = 2 * r + ((OPT && (int)r == rstar && e0 + j < next_arc) ? 1u : 0u);
-                if (rc < 0) take_if_better<RULE>(best, rc, r, pos);
+                if (rc < 0) {
+                    take_if_better<RULE>(best, rc, r, pos);
+                    if (OPT) take_if_better<RULE>(range, rc, e0 + j < next_arc ? 1u : 0u, pos);
+                }
             }
         }
     }
@@ -415,10 +441,7 @@ __global__ __launch_bounds__(kResidentThreads) void scan_rc_kernel(const RcParam
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
     }
-    Key best;
-    best.c = 0;
-    best.r = kNone;
-    best.p = kNone;
+    Key best{0, kNone, kNone}, range{0, kNone, kNone};
     typedef long v2l __attribute__((ext_vector_type(2)));
     const int step = gridDim.x * tile * UNROLL;
     for (int i0 = blockIdx.x * tile * UNROLL + tid * kArcsPerThread; i0 < p.count_padded; i0 += step) {
@@ -434,10 +457,10 @@ __global__ __launch_bounds__(kResidentThreads) void scan_rc_kernel(const RcParam
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int64_t d[4] = {a[u].x, a[u].y, b[u].x, b[u].y};
-            fold_rc<RULE, OPT>(st4[u], d, p.base + i0 + u * tile, p.m_s, p.next_arc, p.block_size, p.rstar, best);
+            fold_rc<RULE, OPT>(st4[u], d, p.base + i0 + u * tile, p.m_s, p.next_arc, p.block_size, p.rstar, best, range);
         }
     }
-    publish_best<RULE, false, kResidentThreads>(best, p.slots + (size_t)blockIdx.x * kSlotStride, p.seq, true);
+    publish_best<RULE, false, kResidentThreads, kDual<RULE, OPT>>(best, p.slots + (size_t)blockIdx.x * kSlotStride, p.seq, true, range);
 }
 
 // d[e] = cost[e] + pi[source[e]] - pi[target[e]] for every stored arc (upload, mcf_engine_patch_arcs); padding arcs have state 0
@@ -521,19 +544,16 @@ __global__ __launch_bounds__(kResidentThreads) void scan_kernel_lds(const ScanPa
     }
     for (int i = tid; i < n_nodes; i += kResidentThreads) lpi[i] = p.pi[i];
     __syncthreads();
-    Key best;
-    best.c = 0;
-    best.r = kNone;
-    best.p = kNone;
+    Key best{0, kNone, kNone}, range{0, kNone, kNone};
     const int step = gridDim.x * UNROLL * kResidentTile;     // UNROLL tiles per step: all their streamed loads are in flight together
     for (int i0 = blockIdx.x * UNROLL * kResidentTile + tid * kArcsPerThread; i0 < p.count_padded; i0 += step) {
         TileData<T> d[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) load_tile<T>(p.src, p.tgt, p.cost, p.state, i0 + u * kResidentTile, d[u]);
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) eval_tile<T, RULE, OPT>(d[u], lpi, p.base + i0 + u * kResidentTile, p.m_s, p.next_arc, p.block_size, p.rstar, best);
+        for (int u = 0; u < UNROLL; ++u) eval_tile<T, RULE, OPT>(d[u], lpi, p.base + i0 + u * kResidentTile, p.m_s, p.next_arc, p.block_size, p.rstar, best, range);
     }
-    publish_best<RULE, false, kResidentThreads>(best, p.slots + (size_t)blockIdx.x * kSlotStride, p.seq, true);
+    publish_best<RULE, false, kResidentThreads, kDual<RULE, OPT>>(best, p.slots + (size_t)blockIdx.x * kSlotStride, p.seq, true, range);
 }
 
 // ------------------------------------------------------------------------------------------------ resident mode
@@ -933,23 +953,20 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
             else eval_tile_best2<T>(mine, pi_view, p.base + my_i0, c1, p1, c2, p2, sub_node, v0);
             publish_candidates(c1, p1, c2, p2, p.slots, seq);
         } else {
-            Key best;
-            best.c = 0;
-            best.r = kNone;
-            best.p = kNone;
+            Key best{0, kNone, kNone}, range{0, kNone, kNone};
             if (PIREG) {
-                fold_tile<T, RULE, OPT>(mine, ps, pt, p.base + my_i0, p.m_s, next_arc, block_size, rstar, best);
+                fold_tile<T, RULE, OPT>(mine, ps, pt, p.base + my_i0, p.m_s, next_arc, block_size, rstar, best, range);
             } else if (REG) {
-                eval_tile<T, RULE, OPT>(mine, pi_view, p.base + my_i0, p.m_s, next_arc, block_size, rstar, best, sub_node, v0);
+                eval_tile<T, RULE, OPT>(mine, pi_view, p.base + my_i0, p.m_s, next_arc, block_size, rstar, best, range, sub_node, v0);
             } else {
                 for (int i0 = my_i0; i0 < p.count_padded; i0 += gridDim.x * nt * kArcsPerThread) {
                     TileData<T> d;
                     load_tile<T>(p.src, p.tgt, p.cost, p.state, i0, d);
-                    eval_tile<T, RULE, OPT, PERM>(d, pi_view, p.base + i0, p.m_s, next_arc, block_size, rstar, best, -1, (T)0, p.orig, p.base);
+                    eval_tile<T, RULE, OPT, PERM>(d, pi_view, p.base + i0, p.m_s, next_arc, block_size, rstar, best, range, -1, (T)0, p.orig, p.base);
                 }
                 if (PERM && best.p != kNone) best.p = (uint32_t)p.orig[(int)best.p - p.base];
             }
-            publish_best<RULE, true, kResidentThreads>(best, p.slots + (size_t)blockIdx.x * kSlotStride, seq, true);
+            publish_best<RULE, true, kResidentThreads, kDual<RULE, OPT>>(best, p.slots + (size_t)blockIdx.x * kSlotStride, seq, true, range);
         }
         last = seq;
         applied = 0;
@@ -1168,10 +1185,7 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
         // per request when every wave issued one).  The LDS variant never reads d from memory again.
         if (!LD && n_pi) asm volatile("buffer_inv sc0\n\ts_waitcnt vmcnt(0)" ::: "memory");
         // ---- scan
-        Key best;
-        best.c = 0;
-        best.r = kNone;
-        best.p = kNone;
+        Key best{0, kNone, kNone}, range{0, kNone, kNone};
         int64_t c1 = 0, c2 = 0;              // CAND: best and second best of this thread's arcs
         uint32_t p1 = kNone, p2 = kNone;
         if (LD) {
@@ -1179,7 +1193,7 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
                 const uint32_t st4 = *reinterpret_cast<const uint32_t *>(ls + i);
                 const int64_t d[4] = {ld[i], ld[i + 1], ld[i + 2], ld[i + 3]};
                 if (CAND) fold_rc_best2(st4, d, p.base + w_lo + i, c1, p1, c2, p2);
-                else fold_rc<RULE, OPT>(st4, d, p.base + w_lo + i, p.m_s, next_arc, block_size, rstar, best);
+                else fold_rc<RULE, OPT>(st4, d, p.base + w_lo + i, p.m_s, next_arc, block_size, rstar, best, range);
             }
         } else {
             typedef long v2l __attribute__((ext_vector_type(2)));
@@ -1190,11 +1204,11 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
                 const v2l b = __builtin_nontemporal_load(reinterpret_cast<const v2l *>(p.rc + i0 + 2));
                 const int64_t d[4] = {a.x, a.y, b.x, b.y};
                 if (CAND) fold_rc_best2(st4, d, p.base + i0, c1, p1, c2, p2);
-                else fold_rc<RULE, OPT>(st4, d, p.base + i0, p.m_s, next_arc, block_size, rstar, best);
+                else fold_rc<RULE, OPT>(st4, d, p.base + i0, p.m_s, next_arc, block_size, rstar, best, range);
             }
         }
         if (CAND) publish_candidates(c1, p1, c2, p2, p.slots, seq);
-        else publish_best<RULE, true, kResidentThreads>(best, p.slots + (size_t)blockIdx.x * kSlotStride, seq, true);
+        else publish_best<RULE, true, kResidentThreads, kDual<RULE, OPT>>(best, p.slots + (size_t)blockIdx.x * kSlotStride, seq, true, range);
         last = seq;
         served += 1;
         idle_since = __builtin_amdgcn_s_memrealtime();
@@ -1205,22 +1219,23 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
 
 // The RCCL exchange of sharded engines wants this shard's candidate in DEVICE memory (the all-gather's send buffer): one workgroup folds the
 // scan's per-workgroup records -- written to device memory in that mode -- with the rule's ordering, exactly as the host's collect() does.
+// dual: the records' second half holds the range keys of OPTIMIZED Block Search; they are folded into the candidate's range_* fields.
 template <int RULE>
-__global__ __launch_bounds__(kThreads) void reduce_records_kernel(const Slot *slots, int grid, int m_s, int na, int next_arc, int block_size, int rstar, mcf_candidate *out)
+__device__ __forceinline__ Key fold_records(const Slot *slots, int grid, int m_s, int na, int next_arc, int block_size, int rstar, bool range_keys, Key *wave_best)
 {
     const int tid = threadIdx.x;
-    Key best;
-    best.c = 0;
-    best.r = kNone;
-    best.p = kNone;
+    Key best{0, kNone, kNone};
     for (int g = tid; g < grid; g += kThreads) {
-        const Slot s = slots[(size_t)g * kSlotStride];
+        const Slot s = slots[(size_t)g * kSlotStride + (range_keys ? 2 : 0)];
         if (s.p == kNone) continue;
         uint32_t r = 0;
         if (RULE == MCF_RULE_BLOCK_SEARCH) {
-            r = s.p / (uint32_t)block_size;
             const int arc = (int)(((uint64_t)s.p + (uint32_t)na) % (uint32_t)m_s);
-            r = 2 * r + ((rstar >= 0 && (int)r == rstar && arc < next_arc) ? 1u : 0u);
+            if (range_keys) r = arc < na ? 1u : 0u;
+            else {
+                r = s.p / (uint32_t)block_size;
+                r = 2 * r + ((rstar >= 0 && (int)r == rstar && arc < next_arc) ? 1u : 0u);
+            }
         }
         if (best.p == kNone) { best.c = s.c; best.r = r; best.p = s.p; }
         else take_if_better<RULE>(best, s.c, r, s.p);
@@ -1228,21 +1243,34 @@ __global__ __launch_bounds__(kThreads) void reduce_records_kernel(const Slot *sl
     // "none" must lose against every record: give it the largest key of the rule's ordering before the butterflies
     if (best.p == kNone) { best.c = INT64_MAX; best.r = kNone; }
     best = wave_min<RULE>(best);
-    __shared__ Key wave_best[kThreads / 64];
+    __syncthreads();                                  // wave_best may still be read from the previous fold
     if ((tid & 63) == 0) wave_best[tid >> 6] = best;
     __syncthreads();
-    if (tid == 0) {
-        Key k = wave_best[0];
-        for (int w = 1; w < kThreads / 64; ++w) {
-            const Key o = wave_best[w];
-            if (o.p == kNone) continue;
-            if (k.p == kNone) k = o;
-            else take_if_better<RULE>(k, o.c, o.r, o.p);
-        }
+    Key k = wave_best[0];
+    for (int w = 1; w < kThreads / 64; ++w) {
+        const Key o = wave_best[w];
+        if (o.p == kNone) continue;
+        if (k.p == kNone) k = o;
+        else take_if_better<RULE>(k, o.c, o.r, o.p);
+    }
+    return k;
+}
+
+template <int RULE>
+__global__ __launch_bounds__(kThreads) void reduce_records_kernel(const Slot *slots, int grid, int m_s, int na, int next_arc, int block_size, int rstar, int dual, mcf_candidate *out)
+{
+    __shared__ Key wave_best[kThreads / 64];
+    const Key k = fold_records<RULE>(slots, grid, m_s, na, next_arc, block_size, rstar, false, wave_best);
+    Key q{0, kNone, kNone};
+    if (dual) q = fold_records<RULE>(slots, grid, m_s, na, next_arc, block_size, rstar, true, wave_best);
+    if (threadIdx.x == 0) {
         mcf_candidate c;
         c.reduced_cost = k.p == kNone ? 0 : k.c;
         c.pos = k.p;
         c.arc = k.p == kNone ? -1 : (RULE == MCF_RULE_BEST_ELIGIBLE ? (int32_t)k.p : (int32_t)(((uint64_t)k.p + (uint32_t)na) % (uint32_t)m_s));
+        c.range_cost = q.p == kNone ? 0 : q.c;
+        c.range_pos = q.p;
+        c.range_arc = q.p == kNone ? -1 : (int32_t)(((uint64_t)q.p + (uint32_t)na) % (uint32_t)m_s);
         *out = c;
     }
 }

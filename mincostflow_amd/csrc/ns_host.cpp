@@ -33,6 +33,7 @@ struct mcf_ns {
     int search_arcs = 0, all_arcs = 0;
     int supply_type = MCF_SUPPLY_GEQ, rule = MCF_RULE_BLOCK_SEARCH;   // NS.cs:38, :77
     bool optimized_pivot = false;                                      // NS.cs:34
+    int vector_width = MCF_VECTOR_DEFAULT;                             // Vector<long>.Count of the reference's host (BSPO.cs:74): mcf_ns_set_vector_width
     int device = 0, int_width = 0, block_size = 0, engine_flags = 0;
     bool auto_config = true;                                           // NS.cs:90
     mcf_block_config config{};                                         // _optimizationConfig, NS.cs:89
@@ -675,6 +676,14 @@ int mcf_ns_enable_optimized_pivot(mcf_ns *s, int32_t enable)
     s->optimized_pivot = enable != 0;
     return MCF_OK;
 }
+int mcf_ns_set_vector_width(mcf_ns *s, int32_t vector_width)
+{
+    if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
+    if (vector_width != MCF_VECTOR_DEFAULT && vector_width != MCF_VECTOR_NONE && vector_width != 2 && vector_width != 4 && vector_width != 8)
+        return mcf::fail(MCF_ERR_INVALID, "vector_width %d is not Vector<long>.Count of any machine (2, 4, 8, MCF_VECTOR_NONE, or 0 = 4)", vector_width);
+    s->vector_width = vector_width;
+    return MCF_OK;
+}
 int mcf_ns_set_optimization_config(mcf_ns *s, const mcf_block_config *config)       // NS.cs:557-561
 {
     if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
@@ -826,6 +835,7 @@ int mcf_ns_prepare(mcf_ns *s)
     s->allow_smaller_side = d.int_width == 64 && !(getenv("MCF_NS_SMALLER_SIDE") && getenv("MCF_NS_SMALLER_SIDE")[0] == '0');
     d.rule = s->rule;
     d.semantics = s->optimized_pivot ? MCF_SEM_OPTIMIZED : MCF_SEM_PLAIN;
+    d.vector_width = s->vector_width;
     d.block_size = s->block_size;
     d.device = s->device;
     d.flags = s->engine_flags;
@@ -877,7 +887,7 @@ int mcf_ns_prepare(mcf_ns *s)
         }
         s->reload_min_engines = all ? std::max<int32_t>(lo, kWalkHintMin) : 0;
     }
-    s->cands.assign((size_t)std::max(1, s->world), mcf_candidate{0, 0xFFFFFFFFu, -1});
+    s->cands.assign((size_t)std::max(1, s->world), mcf_candidate{0, 0xFFFFFFFFu, -1, 0, 0xFFFFFFFFu, -1});
     if (s->shard_mode == mcf_ns::kHost) { rc = mcf_exchange_open(&s->exchange, s->exchange_name.c_str(), s->rank, s->world); if (rc) return rc; }
     s->metrics.config_flags = s->config.flags;
     if (!s->optimized_pivot && (s->config.flags & MCF_OPT_REDUCED_COST_CACHING) && s->rule == MCF_RULE_BLOCK_SEARCH) {

@@ -384,11 +384,14 @@ int collect(mcf_engine *e, int grid, Key *out)
         return len1 % e->block_size ? len1 / e->block_size : -1;
     }();
     const int na = e->next_arc >= e->d.search_arc_num ? 0 : e->next_arc;
+    // OPTIMIZED Block Search: records 0, 1 of a line = the block key, records 2, 3 = the range key (kernels.hip.h: kDual)
+    const bool dual = block_rule && e->d.semantics == MCF_SEM_OPTIMIZED;
+    Key range{0, kNone, kNone};
     for (int g = 0; g < grid; ++g) {
         uint64_t spins = 0;
         auto ready = [&](const volatile Slot &r) { const int64_t c = r.c; const uint32_t q = r.p; return r.tag == record_tag(seq, c, q); };
-        while (!(ready(slots[(size_t)g * stride]) && ready(slots[(size_t)g * stride + 1]) && slots[(size_t)g * stride].c == slots[(size_t)g * stride + 1].c &&
-                 slots[(size_t)g * stride].p == slots[(size_t)g * stride + 1].p)) {
+        auto pair_ready = [&](const volatile Slot *r) { return ready(r[0]) && ready(r[1]) && r[0].c == r[1].c && r[0].p == r[1].p; };
+        while (!(pair_ready(slots + (size_t)g * stride) && (!dual || pair_ready(slots + (size_t)g * stride + 2)))) {
             _mm_pause();
             if (e->resident_running && (spins & 0xFFF) == 0xFFF && ((const volatile uint32_t *)e->h_exit)[0] != 0) {
                 int rc = resident_restart(e);
@@ -417,7 +420,17 @@ int collect(mcf_engine *e, int grid, Key *out)
             take = best.p == kNone || k.r < best.r || (k.r == best.r && (k.c < best.c || (k.c == best.c && k.p < best.p)));
         }
         if (take) best = k;
+        if (dual) {
+            Key q;
+            q.c = slots[(size_t)g * stride + 2].c;
+            q.p = slots[(size_t)g * stride + 2].p;
+            if (q.p != kNone) {
+                q.r = (int)((q.p + (uint32_t)na) % (uint32_t)e->d.search_arc_num) < na ? 1u : 0u;
+                if (range.p == kNone || q.r < range.r || (q.r == range.r && (q.c < range.c || (q.c == range.c && q.p < range.p)))) range = q;
+            }
+        }
     }
+    e->range_key = range;
     e->wait_ticks += (double)__rdtsc() - t0;
     *out = best;
     return MCF_OK;

@@ -32,6 +32,13 @@ class SolverStatus:                   # Types/SolverStatus.cs
     NotSolved, Optimal, Infeasible, Unbounded, Unbalanced = 0, 1, 2, 3, 4
 
 
+def _vector_width_abi(v: int) -> int:
+    """Python side: 0 = not hardware accelerated, 2 / 4 / 8 = Vector<long>.Count (the oracle's convention).  C ABI: MCF_VECTOR_NONE = -1, 0 = default (4)."""
+    if v not in (0, 2, 4, 8):
+        raise ValueError(f"vector_width {v} is not one of 0, 2, 4, 8")
+    return L.VECTOR_NONE if v == 0 else v
+
+
 def _i32(a): return np.ascontiguousarray(a, np.int32)
 def _i64(a): return np.ascontiguousarray(a, np.int64)
 def _i8(a): return np.ascontiguousarray(a, np.int8)
@@ -159,6 +166,11 @@ class NetworkSimplex:
 
     def enable_optimized_pivot(self, enable: bool = True):     # NetworkSimplex.cs:532-535
         L.check(L.lib().mcf_ns_enable_optimized_pivot(self._h, int(enable))); return self
+
+    def set_vector_width(self, vector_width: int):
+        """Vector<long>.Count of the machine whose EnableOptimizedPivot(true) Block Search is reproduced: 4 (x64, the default), 2, 8, or
+        0 = Vector.IsHardwareAccelerated is false (BlockSearchPivotOptimized.cs:74, :115; the reference reads the property, it has no setter)."""
+        L.check(L.lib().mcf_ns_set_vector_width(self._h, _vector_width_abi(vector_width))); return self
 
     # --- NetworkSimplex.cs:549-570
     def set_optimization_config(self, config):                 # SetOptimizationConfig: switches auto-configuration off
@@ -342,9 +354,9 @@ class PivotEngine:
     """Device-resident SoA + pivot rules (mcf_engine_* of include/mcf_hip.h)."""
 
     def __init__(self, node_count: int, arc_capacity: int, search_arc_num: int, rule=PivotRule.BlockSearch,
-                 optimized=True, int_width=64, block_size=0, device=0, shard=(0, 0), scan_workgroups=0, flags=0, resident_workgroups=0):
+                 optimized=True, int_width=64, block_size=0, device=0, shard=(0, 0), scan_workgroups=0, flags=0, resident_workgroups=0, vector_width=4):
         d = L.EngineDesc(node_count, arc_capacity, search_arc_num, int_width, rule, L.SEM_OPTIMIZED if optimized else L.SEM_PLAIN,
-                         block_size, device, shard[0], shard[1], scan_workgroups, flags, resident_workgroups)
+                         block_size, device, shard[0], shard[1], scan_workgroups, flags, resident_workgroups, _vector_width_abi(vector_width))
         self._h = C.c_void_p()
         L.check(L.lib().mcf_engine_create(C.byref(self._h), C.byref(d)))
         self.node_count, self.arc_capacity, self.search_arc_num = node_count, arc_capacity, search_arc_num
@@ -502,10 +514,10 @@ def shard_range(search_arc_num: int, rank: int, world: int):
     return b.value, e.value
 
 
-def resolve_candidates(rule: int, optimized: bool, search_arc_num: int, block_size: int, next_arc: int, cands):
+def resolve_candidates(rule: int, optimized: bool, search_arc_num: int, block_size: int, next_arc: int, cands, vector_width=4):
     """Engine-free MINLOC over per-shard candidates; returns (found, arc, reduced_cost, new_next_arc)."""
     arr = (L.Candidate * len(cands))(*cands)
     na, f, a, c = C.c_int32(next_arc), C.c_int32(), C.c_int32(), C.c_int64()
-    L.check(L.lib().mcf_resolve_candidates(rule, L.SEM_OPTIMIZED if optimized else L.SEM_PLAIN, search_arc_num, block_size,
+    L.check(L.lib().mcf_resolve_candidates(rule, L.SEM_OPTIMIZED if optimized else L.SEM_PLAIN, _vector_width_abi(vector_width), search_arc_num, block_size,
                                            C.byref(na), len(cands), arr, C.byref(f), C.byref(a), C.byref(c)))
     return bool(f.value), a.value, c.value, na.value

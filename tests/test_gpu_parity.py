@@ -24,12 +24,12 @@ def _random_soa(rng, m_s, n, cost_span, pi_span, extra=7):
                 pi=rng.integers(-pi_span, 1, n, dtype=np.int64))
 
 
-def _oracle_scan(rule, optimized, a, m_s, block, next_arc):
+def _oracle_scan(rule, optimized, a, m_s, block, next_arc, vw=4):
     if rule == O.RULE_BEST:
         f, e, c = O.scan_best(m_s, a["state"], a["cost"], a["src"], a["tgt"], a["pi"]); return f, e, c, next_arc
     if rule == O.RULE_FIRST:
         return O.scan_first(m_s, a["state"], a["cost"], a["src"], a["tgt"], a["pi"], next_arc)
-    return O.scan_block(m_s, a["state"], a["cost"], a["src"], a["tgt"], a["pi"], block, optimized, next_arc)
+    return O.scan_block(m_s, a["state"], a["cost"], a["src"], a["tgt"], a["pi"], block, optimized, next_arc, vector_width=vw)
 
 
 # default = resident grid, with the candidate cache where it applies (Best Eligible, register-resident arcs, sparse graph)
@@ -54,16 +54,22 @@ def _mode_flags(mode, monkeypatch):
     return mode
 
 
+# (rule, EnableOptimizedPivot flavour, Vector<long>.Count of the reference's host: 4 = x64, 0 = not hardware accelerated; only the optimized
+# Block Search reads it -- BlockSearchPivotOptimized.cs:74-99)
+RULE_CASES = [pytest.param(O.RULE_BEST, True, 4, id="best"), pytest.param(O.RULE_BLOCK, True, 4, id="block-opt-v4"), pytest.param(O.RULE_BLOCK, True, 0, id="block-opt-v0"),
+              pytest.param(O.RULE_BLOCK, True, 8, id="block-opt-v8"), pytest.param(O.RULE_BLOCK, False, 4, id="block-plain"), pytest.param(O.RULE_FIRST, True, 4, id="first")]
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("width", [64, 32])
-@pytest.mark.parametrize("rule,optimized", [(O.RULE_BEST, True), (O.RULE_BLOCK, True), (O.RULE_BLOCK, False), (O.RULE_FIRST, True)])
-def test_scan_matches_oracle_on_random_arrays(width, rule, optimized, mode, monkeypatch):
+@pytest.mark.parametrize("rule,optimized,vw", RULE_CASES)
+def test_scan_matches_oracle_on_random_arrays(width, rule, optimized, vw, mode, monkeypatch):
     """Ragged sizes, heavy ties (tiny cost range), random patches between searches (short lists, long lists), in both
     engine modes: the resident grid fed through the mailbox and one dispatch per search."""
     rc_layout = isinstance(mode, str)
     rc_resident = rc_layout and mode != "rc"
     mode = _mode_flags(mode, monkeypatch)
-    rng = np.random.default_rng(1234 + width + 10 * rule + optimized)
+    rng = np.random.default_rng(1234 + width + 10 * rule + optimized + 100 * vw)
     for m_s, n, span in [(1, 2, 3), (3, 2, 2), (4, 5, 2), (5, 3, 50), (1023, 40, 3), (1024, 300, 2), (1025, 7, 10 ** 6),
                          (4097, 5000, 4), (100003, 20000, 10 ** 4), (2 ** 20 + 5, 3000, 10 ** 5),
                          # potentials too many for LDS: register-resident potentials (<= 512 threads per workgroup) and, at 600k arcs, without
@@ -72,15 +78,15 @@ def test_scan_matches_oracle_on_random_arrays(width, rule, optimized, mode, monk
         pi_span = 10 ** 9 if width == 64 and span > 100 else span * 3
         a = _random_soa(rng, m_s, n, span, pi_span)
         block = int(rng.integers(1, max(2, min(m_s, 700))))
-        eng = M.PivotEngine(n, len(a["src"]), m_s, rule=RULES[rule], optimized=optimized, int_width=width, block_size=block, flags=mode)
+        eng = M.PivotEngine(n, len(a["src"]), m_s, rule=RULES[rule], optimized=optimized, int_width=width, block_size=block, flags=mode, vector_width=vw)
         eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
         next_arc = 0
         for it in range(12):
-            f, e, c, na = _oracle_scan(rule, optimized, a, m_s, block, next_arc)
+            f, e, c, na = _oracle_scan(rule, optimized, a, m_s, block, next_arc, vw)
             f2, e2, c2 = eng.find_entering()
             assert f2 == f, (m_s, it)
             if f:
-                assert (e2, c2) == (e, c), (m_s, it, rule, optimized, e2, e, c2, c, next_arc, block)
+                assert (e2, c2) == (e, c), (m_s, it, rule, optimized, vw, e2, e, c2, c, next_arc, block)
                 if rule != O.RULE_BEST:
                     assert eng.next_arc == na, (m_s, it, eng.next_arc, na, next_arc, block, e)
                 next_arc = na
@@ -154,13 +160,13 @@ def test_scan_edge_cases():
     assert ei.value.code == L.ERR_INVALID
 
 
-def _solve_both(p, sem, rule, int_width=0, flags=0, supply_type=O.GEQ, block_size=0, auto=True, config=None):
+def _solve_both(p, sem, rule, int_width=0, flags=0, supply_type=O.GEQ, block_size=0, auto=True, config=None, vw=4):
     """auto: the reference's auto-configuration (its default, NetworkSimplex.cs:90) on both sides; config: dict of OptimizationConfig
     fields given to SetOptimizationConfig on both sides (switches auto-configuration off, NetworkSimplex.cs:557-561)."""
-    o = O.Oracle(p, sem, rule, supply_type=supply_type, block_size=block_size, auto_config=auto and config is None, config=config)
+    o = O.Oracle(p, sem, rule, supply_type=supply_type, block_size=block_size, auto_config=auto and config is None, config=config, vector_width=vw)
     st_o, tr_o = o.solve(trace_cap=4_000_000)
     ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
-    ns.set_pivot_rule(RULES[rule]).enable_optimized_pivot(sem == O.SEM_CSHARP_OPT).set_supply_type(supply_type)
+    ns.set_pivot_rule(RULES[rule]).enable_optimized_pivot(sem == O.SEM_CSHARP_OPT).set_supply_type(supply_type).set_vector_width(vw)
     if config is not None:
         ns.set_optimization_config(M.block_config(**config))
     elif not auto:
@@ -179,15 +185,16 @@ def test_solve_is_pivot_for_pivot_identical(name, mode, monkeypatch):
     rc_resident = rc_layout and mode != "rc"
     mode = _mode_flags(mode, monkeypatch)
     p = load(name)
-    for sem, rule in [(O.SEM_CSHARP_OPT, O.RULE_BLOCK), (O.SEM_CSHARP, O.RULE_BLOCK), (O.SEM_CSHARP_OPT, O.RULE_BEST),
-                      (O.SEM_CSHARP, O.RULE_BEST), (O.SEM_CSHARP_OPT, O.RULE_FIRST), (O.SEM_CSHARP, O.RULE_FIRST)]:
+    # the optimized Block Search as the reference runs it on x64 (Vector<long>.Count = 4), on NEON (2) and without hardware vectors (0)
+    for sem, rule, vw in [(O.SEM_CSHARP_OPT, O.RULE_BLOCK, 4), (O.SEM_CSHARP_OPT, O.RULE_BLOCK, 0), (O.SEM_CSHARP_OPT, O.RULE_BLOCK, 2), (O.SEM_CSHARP, O.RULE_BLOCK, 4),
+                          (O.SEM_CSHARP_OPT, O.RULE_BEST, 4), (O.SEM_CSHARP, O.RULE_BEST, 4), (O.SEM_CSHARP_OPT, O.RULE_FIRST, 4), (O.SEM_CSHARP, O.RULE_FIRST, 4)]:
         if name == "AURV19V6" and rule == O.RULE_FIRST:
             continue        # 117k pivots, nothing new
-        o, st_o, tr_o, ns, st = _solve_both(p, sem, rule, flags=mode)
+        o, st_o, tr_o, ns, st = _solve_both(p, sem, rule, flags=mode, vw=vw)
         tr = ns.trace()
         assert st == st_o == O.OPTIMAL
-        assert len(tr) == len(tr_o) == o.n_pivots, (name, sem, rule, len(tr), len(tr_o))
-        assert np.array_equal(tr, tr_o), (name, sem, rule, int(np.argmax(tr != tr_o)))
+        assert len(tr) == len(tr_o) == o.n_pivots, (name, sem, rule, vw, len(tr), len(tr_o))
+        assert np.array_equal(tr, tr_o), (name, sem, rule, vw, int(np.argmax(tr != tr_o)))
         assert ns.get_total_cost() == o.total_cost
         assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
         m = ns.get_metrics()
@@ -310,23 +317,25 @@ def test_staged_update_path_equals_inline_path():
     assert e["resident"] or (e["timed_scans"] > 10 and e["timed_scan_ns"] > 0)
 
 
-@pytest.mark.parametrize("rule,optimized", [(O.RULE_BEST, True), (O.RULE_BLOCK, True), (O.RULE_BLOCK, False), (O.RULE_FIRST, True)])
-def test_sharded_engines_resolve_like_one_engine(rule, optimized):
+@pytest.mark.parametrize("rule,optimized,vw", RULE_CASES)
+def test_sharded_engines_resolve_like_one_engine(rule, optimized, vw):
     """Arc shards on separate engines + the MINLOC resolve step give the single-engine answer (same device; the RCCL
     all-gather only moves the 16-byte records)."""
     rng = np.random.default_rng(99 + rule)
     m_s, n, world = 50021, 3000, 3
     a = _random_soa(rng, m_s, n, 5, 12, extra=0)
     block = 173
-    one = M.PivotEngine(n, m_s, m_s, rule=RULES[rule], optimized=optimized, block_size=block)
+    one = M.PivotEngine(n, m_s, m_s, rule=RULES[rule], optimized=optimized, block_size=block, vector_width=vw)
     one.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
     shards = []
     for r in range(world):
-        e = M.PivotEngine(n, m_s, m_s, rule=RULES[rule], optimized=optimized, block_size=block, shard=M.shard_range(m_s, r, world))
+        e = M.PivotEngine(n, m_s, m_s, rule=RULES[rule], optimized=optimized, block_size=block, shard=M.shard_range(m_s, r, world), vector_width=vw)
         e.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
         shards.append(e)
     for it in range(10):
+        na0 = one.next_arc
         want = one.find_entering()
+        assert want == _oracle_scan(rule, optimized, a, m_s, block, na0, vw)[:3]
         cands = [e.find_entering_local() for e in shards]
         got = [e.resolve(cands) for e in shards]
         assert all(g == want for g in got), (it, want, got)
@@ -334,6 +343,8 @@ def test_sharded_engines_resolve_like_one_engine(rule, optimized):
         if want[0]:
             arcs = np.array([want[1]], np.int32); vals = np.array([0], np.int8)
             nodes = rng.choice(n, size=40, replace=False).astype(np.int32)
+            a["state"][arcs] = vals
+            a["pi"][nodes] += -3
             for e in [one] + shards:
                 e.patch_state(arcs, vals)
                 e.update_potential(nodes, -3)
@@ -351,13 +362,14 @@ def test_sharded_solve_through_the_rccl_exchange(layout, monkeypatch):
     else:
         g = M.netgen_like(7, 20_000, 60_000, 100, 100)
         p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
-    for sem, rule in [(O.SEM_CSHARP_OPT, O.RULE_BEST), (O.SEM_CSHARP_OPT, O.RULE_BLOCK), (O.SEM_CSHARP, O.RULE_BLOCK), (O.SEM_CSHARP_OPT, O.RULE_FIRST)]:
+    for sem, rule, vw in [(O.SEM_CSHARP_OPT, O.RULE_BEST, 4), (O.SEM_CSHARP_OPT, O.RULE_BLOCK, 4), (O.SEM_CSHARP_OPT, O.RULE_BLOCK, 0), (O.SEM_CSHARP, O.RULE_BLOCK, 4),
+                          (O.SEM_CSHARP_OPT, O.RULE_FIRST, 4)]:
         if layout != "lds-potentials" and rule == O.RULE_FIRST:
             continue        # hundreds of thousands of pivots, nothing new
-        o = O.Oracle(p, sem, rule, auto_config=True)
+        o = O.Oracle(p, sem, rule, auto_config=True, vector_width=vw)
         st_o, tr_o = o.solve(trace_cap=1 << 22)
         ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
-        ns.set_pivot_rule(RULES[rule]).enable_optimized_pivot(sem == O.SEM_CSHARP_OPT).record_trace(1 << 22)
+        ns.set_pivot_rule(RULES[rule]).enable_optimized_pivot(sem == O.SEM_CSHARP_OPT).set_vector_width(vw).record_trace(1 << 22)
         ns.set_sharding(M.comm_unique_id(), 0, 1)
         assert ns.solve() == st_o == 1
         assert np.array_equal(ns.trace(), tr_o) and ns.get_total_cost() == o.total_cost
@@ -884,20 +896,20 @@ def test_raw_engine_adapts_its_block_size_per_request():
 # ------------------------------------------------------------------ arc shards: resident shard engines, in-process shard groups, BASELINE config 5
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rule,optimized", [(O.RULE_BEST, True), (O.RULE_BLOCK, True), (O.RULE_BLOCK, False), (O.RULE_FIRST, True)])
-def test_resident_shard_engines_resolve_like_one_engine(rule, optimized):
+@pytest.mark.parametrize("rule,optimized,vw", RULE_CASES)
+def test_resident_shard_engines_resolve_like_one_engine(rule, optimized, vw):
     """The shard test above with every shard served by its own RESIDENT grid (co-resident on this GPU: MCF_ENGINE_SHARE_DEVICE and a
     grid cap), searches posted to all shards first and collected afterwards (mcf_engine_search_begin / _search_end_local)."""
     rng = np.random.default_rng(199 + rule)
     m_s, n, world = 150_011, 30_000, 3
     a = _random_soa(rng, m_s, n, 5, 12, extra=0)
     block = 173
-    one = M.PivotEngine(n, m_s, m_s, rule=RULES[rule], optimized=optimized, block_size=block, flags=M.ENGINE_DISPATCH)
+    one = M.PivotEngine(n, m_s, m_s, rule=RULES[rule], optimized=optimized, block_size=block, flags=M.ENGINE_DISPATCH, vector_width=vw)
     one.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
     shards = []
     for r in range(world):
         e = M.PivotEngine(n, m_s, m_s, rule=RULES[rule], optimized=optimized, block_size=block, shard=M.shard_range(m_s, r, world),
-                          flags=M.ENGINE_SHARE_DEVICE, resident_workgroups=64)
+                          flags=M.ENGINE_SHARE_DEVICE, resident_workgroups=64, vector_width=vw)
         e.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
         assert e.stats()["resident"] == 1
         shards.append(e)
@@ -926,20 +938,20 @@ def test_shard_group_solves_pivot_for_pivot(shards):
     """mcf_ns_set_shard_group: one host thread, R engines (here co-resident on one GPU) each holding an arc shard, host-side MINLOC over
     their answers -- the pivot sequence of the un-sharded solve, for Best Eligible and both Block Search flavours (the plain one with the
     reference's adaptive block size, which every shard has to follow in step)."""
-    cases = [(load("netgen_8_14a"), [(O.SEM_CSHARP_OPT, O.RULE_BEST)]),
-             (None, [(O.SEM_CSHARP_OPT, O.RULE_BEST), (O.SEM_CSHARP_OPT, O.RULE_BLOCK), (O.SEM_CSHARP, O.RULE_BLOCK)])]
+    cases = [(load("netgen_8_14a"), [(O.SEM_CSHARP_OPT, O.RULE_BEST, 4)]),
+             (None, [(O.SEM_CSHARP_OPT, O.RULE_BEST, 4), (O.SEM_CSHARP_OPT, O.RULE_BLOCK, 4), (O.SEM_CSHARP_OPT, O.RULE_BLOCK, 0), (O.SEM_CSHARP, O.RULE_BLOCK, 4)])]
     g = M.netgen_like(7, 20_000, 60_000, 100, 100)
     for p, rules in cases:
         if p is None:
             p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
-        for sem, rule in rules:
-            o = O.Oracle(p, sem, rule, auto_config=True)
+        for sem, rule, vw in rules:
+            o = O.Oracle(p, sem, rule, auto_config=True, vector_width=vw)
             st_o, tr_o = o.solve(trace_cap=4_000_000)
             ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
-            ns.set_pivot_rule(RULES[rule]).enable_optimized_pivot(sem == O.SEM_CSHARP_OPT).record_trace(4_000_000)
+            ns.set_pivot_rule(RULES[rule]).enable_optimized_pivot(sem == O.SEM_CSHARP_OPT).set_vector_width(vw).record_trace(4_000_000)
             ns.set_shard_group([0] * shards)
             assert ns.solve() == st_o == O.OPTIMAL
-            assert np.array_equal(ns.trace(), tr_o), (shards, sem, rule, int(np.argmax(ns.trace()[: len(tr_o)] != tr_o[: len(ns.trace())])))
+            assert np.array_equal(ns.trace(), tr_o), (shards, sem, rule, vw, int(np.argmax(ns.trace()[: len(tr_o)] != tr_o[: len(ns.trace())])))
             assert ns.get_total_cost() == o.total_cost
             assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
             if sem == O.SEM_CSHARP:
