@@ -211,6 +211,15 @@ MCF_API int mcf_engine_reload_potentials(mcf_engine *e, int32_t changed_nodes);
 MCF_API int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, const int32_t *source,
                                   const int32_t *target, const int64_t *cost);
 
+/* Node ids are the host's business: the engine only ever sees them as end points of arcs and as indices into the potentials.  A host
+ * that relabels its nodes (the C++ driver does, in thread order, so that its subtree walks run through memory front to back) tells the
+ * engine with new_of[old id] = new id, a permutation of [0, node_count).  Between two searches; a bound potential array
+ * (mcf_engine_bind_potentials) must already be in the new order, and replaces every potential change announced since the last search.
+ * Arc ids, states and reduced costs are untouched, so no search result changes.  mcf_engine_can_renumber: 0 for the one layout that
+ * orders its arcs by node id (MCF_HIP_BUCKET_NODES). */
+MCF_API int mcf_engine_can_renumber(mcf_engine *e, int32_t *yes);
+MCF_API int mcf_engine_renumber_nodes(mcf_engine *e, const int32_t *new_of);
+
 /* IFindEnteringArc.FindEnteringArc (NS.cs:1286-1289, :1699-1723): blocking.  *found = 0/1; *arc = entering arc;
  * *reduced_cost = state*(cost + pi[source] - pi[target]) of that arc.  Advances the rule's internal next_arc exactly
  * as the selected reference implementation does. */
@@ -294,6 +303,7 @@ typedef struct mcf_engine_stats {
     int64_t rc_layout;            /* 1: reduced costs are kept per arc (large sparse instances) */
     int64_t rc_recomputes;        /* RC layout: potential lists naming more than a sixteenth of the nodes, after which every reduced cost of the
                                      shard was computed again instead of shifting the listed nodes' arcs one by one */
+    int64_t renumberings;         /* mcf_engine_renumber_nodes calls */
 } mcf_engine_stats;
 MCF_API int mcf_engine_get_stats(mcf_engine *e, mcf_engine_stats *out);
 MCF_API int mcf_engine_reset_stats(mcf_engine *e);
@@ -408,6 +418,11 @@ MCF_API int mcf_ns_get_trace_length(mcf_ns *s, int64_t *length);
 MCF_API int mcf_ns_begin(mcf_ns *s, int32_t *status);            /* CheckBounds + TransformToStandardForm + Initialize */
 MCF_API int mcf_ns_apply_pivot(mcf_ns *s, int32_t entering_arc, int32_t *unbounded);   /* FindJoinNode .. UpdatePotentials */
 MCF_API int mcf_ns_finish(mcf_ns *s, int32_t *status);           /* CheckFeasibility + lower-bound restore */
+/* Measurement / test aid: `count` pivots with the given entering arcs applied back to back, no engine involved -- the sequential half
+ * alone, with the walk aids mcf_ns_solve uses (smaller_side != 0: shift whichever side of the tree is smaller; renumber_every > 0: relabel
+ * the nodes in thread order whenever the walks since the last relabelling covered that many times the node count).  Fills the metrics'
+ * tree_update_us / potential_update_us / loop_us (setup_us = time spent relabelling).  Node ids are the caller's again when it returns. */
+MCF_API int mcf_ns_replay(mcf_ns *s, const int32_t *arcs, int64_t count, int32_t smaller_side, double renumber_every);
 /* views of the internal SoA after mcf_ns_begin (valid until destroy); sizes: arc_capacity / node_count + 1 */
 MCF_API int mcf_ns_internal(mcf_ns *s, int32_t *search_arc_num, int32_t *arc_capacity, const int32_t **source,
                             const int32_t **target, const int64_t **cost, const int8_t **state, const int64_t **pi);

@@ -54,7 +54,7 @@ class EngineStats(C.Structure):
                 ("bytes_per_scan", C.c_int64), ("resident", C.c_int64), ("resident_launches", C.c_int64),
                 ("resident_requests", C.c_int64), ("resident_scan_ns", C.c_double), ("resident_kernel_ns", C.c_double), ("candidates", C.c_int64),
                 ("host_decided", C.c_int64), ("arcs_checked", C.c_int64), ("initial_block_size", C.c_int32), ("current_block_size", C.c_int32),
-                ("comm_ranks", C.c_int32), ("reserved", C.c_int32), ("async_refreshes", C.c_int64), ("scan_bytes_read", C.c_int64), ("rc_layout", C.c_int64), ("rc_recomputes", C.c_int64)]
+                ("comm_ranks", C.c_int32), ("reserved", C.c_int32), ("async_refreshes", C.c_int64), ("scan_bytes_read", C.c_int64), ("rc_layout", C.c_int64), ("rc_recomputes", C.c_int64), ("renumberings", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
@@ -132,6 +132,8 @@ SIGNATURES = {
     "mcf_engine_reload_threshold": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mcf_engine_reload_potentials": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_engine_patch_arcs": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, _i64p]),
+    "mcf_engine_can_renumber": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "mcf_engine_renumber_nodes": (C.c_int, [C.c_void_p, _i32p]),
     "mcf_engine_find_entering": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
     "mcf_engine_search_begin": (C.c_int, [C.c_void_p]),
     "mcf_engine_search_end": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
@@ -195,6 +197,7 @@ SIGNATURES = {
     "mcf_ns_begin": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "mcf_ns_apply_pivot": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32)]),
     "mcf_ns_finish": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "mcf_ns_replay": (C.c_int, [C.c_void_p, _i32p, C.c_int64, C.c_int32, C.c_double]),
     "mcf_ns_internal": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(_P(C.c_int32)), _P(_P(C.c_int32)),
                                   _P(_P(C.c_int64)), _P(_P(C.c_int8)), _P(_P(C.c_int64))]),
     "mcf_ns_tree": (C.c_int, [C.c_void_p, _P(_P(C.c_int32)), _P(_P(C.c_int32)), _P(_P(C.c_int32)), _P(_P(C.c_int8)), _P(_P(C.c_int64)), _P(_P(C.c_int64))]),

@@ -1423,6 +1423,99 @@ int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, con
     return MCF_OK;
 }
 
+int mcf_engine_can_renumber(mcf_engine *e, int32_t *yes)
+{
+    if (!e || !yes) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_can_renumber: null argument");
+    *yes = e->bucket_nodes > 0 ? 0 : 1;          // the bucketed layout orders its arcs by target id
+    return MCF_OK;
+}
+
+int mcf_engine_renumber_nodes(mcf_engine *e, const int32_t *new_of)
+{
+    if (!e || !new_of) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_renumber_nodes: null argument");
+    if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
+    if (e->bucket_nodes > 0) return mcf::fail(MCF_ERR_STATE, "mcf_engine_renumber_nodes: the bucketed layout orders its arcs by target id (mcf_engine_can_renumber)");
+    if (e->in_flight != mcf_engine::kNoSearch) return mcf::fail(MCF_ERR_STATE, "mcf_engine_renumber_nodes: a search is in flight");
+    const int n = e->d.node_count;
+    {   // a permutation of [0, n)?
+        std::vector<uint8_t> seen((size_t)n, 0);
+        for (int u = 0; u < n; ++u) {
+            if ((unsigned)new_of[u] >= (unsigned)n || seen[new_of[u]]) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_renumber_nodes: not a permutation (node %d)", u);
+            seen[new_of[u]] = 1;
+        }
+    }
+    HIP_TRY(hipSetDevice(e->d.device));
+    // everything the device has not heard yet goes out under the old ids; a bound potential array has been permuted by its owner already,
+    // so what is pending of it is dropped and the whole array is copied below
+    int rc = resident_stop(e);
+    if (rc) return rc;
+    if (e->ext_pi) {
+        e->pend_node.clear(); e->pend_val.clear(); e->pend_shift = false;
+        e->reload_pi = false;
+        if (e->cand_on) { e->sync_nodes.clear(); e->rc_sync.clear(); e->rc_shift_unknown = false; e->blind_count = 0; }
+    }
+    rc = flush_pending(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    // device: end points, potentials
+    int32_t *d_map = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_map, sizeof(int32_t) * (size_t)n));
+    hipError_t err = hipMemcpy(d_map, new_of, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(renumber_kernel, dim3(e->count_padded / kThreads), dim3(kThreads), 0, e->stream, e->d_src, e->d_tgt, d_map, e->count_padded);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_map);
+    if (err != hipSuccess) return mcf::fail(MCF_ERR_HIP, "mcf_engine_renumber_nodes: %s", hipGetErrorString(err));
+    if (!e->ext_pi) {
+        if (!e->mirror_valid) { rc = mcf_engine_download_pi(e, e->pi.data()); if (rc) return rc; e->mirror_valid = true; }
+        mcf::hvec<int64_t> moved((size_t)n);
+        for (int u = 0; u < n; ++u) moved[new_of[u]] = e->pi[u];
+        std::copy(moved.begin(), moved.end(), e->pi.begin());
+    }
+    {
+        const int64_t *pi = e->ext_pi ? e->ext_pi : e->pi.data();
+        if (e->d.int_width == 32) {
+            std::vector<int32_t> p32((size_t)n);
+            for (int u = 0; u < n; ++u) { if (!fits32(pi[u])) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d does not fit int32", u); p32[u] = (int32_t)pi[u]; }
+            HIP_TRY(hipMemcpy(e->d_pi, p32.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+        } else {
+            HIP_TRY(hipMemcpy(e->d_pi, pi, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice));
+        }
+    }
+    // host mirrors of the candidate cache
+    if (e->cand_on) {
+        const int m_s = e->d.search_arc_num;
+        for (int a = 0; a < m_s; ++a) { e->h_src[a] = new_of[e->h_src[a]]; e->h_tgt[a] = new_of[e->h_tgt[a]]; }
+        cand_build_adjacency(e);
+        mcf::hvec<uint32_t> at((size_t)n);
+        for (int u = 0; u < n; ++u) at[new_of[u]] = e->node_at[u];
+        std::copy(at.begin(), at.end(), e->node_at.begin());
+        for (size_t i = 0; i < e->cand_ends.size(); ++i) e->cand_ends[i] = new_of[e->cand_ends[i]];
+        for (int32_t &u : e->pivot_nodes) u = new_of[u];
+        for (int32_t &u : e->sync_nodes) u = new_of[u];
+        for (auto &x : e->rc_sync) x.node = new_of[x.node];
+    }
+    // RC layout: the reduced costs stay where they are (same arcs, same values); the nodes' arc lists are keyed by node id
+    if (e->rc_mode) {
+        const int cnt = e->end - e->begin;
+        std::vector<int32_t> s2((size_t)std::max(1, cnt)), t2((size_t)std::max(1, cnt));
+        if (e->cand_on) { std::copy(e->h_src.begin() + e->begin, e->h_src.begin() + e->end, s2.begin()); std::copy(e->h_tgt.begin() + e->begin, e->h_tgt.begin() + e->end, t2.begin()); }
+        else {
+            HIP_TRY(hipMemcpy(s2.data(), e->d_src, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(t2.data(), e->d_tgt, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost));
+        }
+        rc = rc_build_adjacency(e, s2.data(), t2.data());
+        // potential changes that were dropped above in favour of the whole array never reached the per-arc reduced costs: all of them again
+        if (!rc) rc = rc_recompute(e);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    e->st.renumberings += 1;
+    return MCF_OK;
+}
+
 int mcf_engine_find_entering(mcf_engine *e, int32_t *found, int32_t *arc, int64_t *reduced_cost)
 {
     if (!e || !found || !arc) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_find_entering: null argument");

@@ -1289,6 +1289,13 @@ __global__ __launch_bounds__(kThreads) void update_kernel(T *pi, const int32_t *
     }
 }
 
+// node ids relabelled by the host (mcf_engine_renumber_nodes): the arcs' end points follow; padding arcs (state 0) just get some valid id
+__global__ __launch_bounds__(kThreads) void renumber_kernel(int32_t *src, int32_t *tgt, const int32_t *new_of, int count_padded)
+{
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < count_padded) { src[i] = new_of[src[i]]; tgt[i] = new_of[tgt[i]]; }
+}
+
 // evicts the caches before a "cold" measurement: reads a large buffer once (no stores, so no dirty lines are left to write back
 // during the measured scan); the sum is kept alive through a store that practically never happens
 __global__ void flush_kernel(uint4 *buf, size_t n16)

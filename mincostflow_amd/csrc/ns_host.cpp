@@ -46,6 +46,14 @@ struct mcf_ns {
     mcf::hvec<int32_t> par, par_arc, nxt, prv, sub, fin;   // Parent, Pred, Thread, RevThread, SuccNum, LastSucc
     mcf::hvec<int8_t> par_dir;
     std::vector<int32_t> scratch;
+    // Node ids in use inside a solve may differ from the caller's: renumber_nodes() relabels the nodes in thread (preorder) order so that the
+    // subtree walks, the cycle searches and the engines' per-node tables run through memory front to back instead of chasing pointers.
+    // new_of[caller's id] = id in use, orig_of = the inverse; empty = identity.  Arc ids never change, so no pivot rule can tell.
+    std::vector<int32_t> new_of, orig_of;
+    int64_t walked_since_renumber = 0, jumps_since_renumber = 0, renumbers = 0;
+    bool allow_renumber = false;
+    double renumber_every = 128.0;    // relabel when the walks since the last relabelling covered this many times the node count
+    double renumber_ticks = 0;
     int64_t sum_supply = 0, art_cost = 0;
     int status = MCF_NOT_SOLVED;
     bool begun = false, transformed = false, prepared = false, solved = false;
@@ -68,8 +76,14 @@ struct mcf_ns {
     int reload_min_engines = 0;       // what the engines asked for (mcf_engine_reload_threshold), 0 when one of them only takes lists
     bool moved_as_reload = false;     // the last walk wrote no node list: the engines reload _pi
     bool allow_smaller_side = false;
-    int64_t dbg_reload_walks = 0;
-    int64_t dbg_hist_n[32] = {0}, dbg_hist_nodes[32] = {0}, dbg_over_half = 0, dbg_over_half_nodes = 0;   // MCF_NS_DEBUG: subtree sizes by log2
+    // MCF_NS_DEBUG only (reset by every mcf_ns_solve): moved subtrees by log2 of their size -- how many, how many nodes, and where their pivots'
+    // time went (ticks): the walk incl. hand-over, the wait for the search that follows, everything else of the pivot
+    struct Debug {
+        bool on = false;
+        int64_t reload_walks = 0, over_half = 0, over_half_nodes = 0;
+        int64_t n[32] = {0}, nodes[32] = {0};
+        double walk[32] = {0}, wait[32] = {0}, rest[32] = {0};
+    } dbg;
     int moved_sent = 0;               // how many of them the engine already has (handed over during the walk)
     int engine_rc = 0;                // first error of an engine call made from inside a pivot
     double piece_ticks = 0;           // time inside the hand-over calls made during the walks (part of the potential-update bucket)
@@ -147,6 +161,12 @@ int engines_search_end(mcf_ns *s, int32_t *found, int32_t *arc)
         return rc;
     }
     }
+}
+int engines_renumber(mcf_ns *s, const int32_t *new_of)
+{
+    int rc = mcf_engine_renumber_nodes(s->engine, new_of);
+    for (size_t i = 0; i < s->peers.size() && !rc; ++i) rc = mcf_engine_renumber_nodes(s->peers[i], new_of);
+    return rc;
 }
 void engines_park(mcf_ns *s)
 {
@@ -433,7 +453,7 @@ void shift_potentials(mcf_ns *s)
         }
         s->moved_as_reload = true;
         s->moved_sent = count;
-        s->dbg_reload_walks += 1;
+        if (s->dbg.on) s->dbg.reload_walks += 1;
         return;
     }
     int32_t *const nodes = s->moved.data();
@@ -507,6 +527,64 @@ int normalise_potentials(mcf_ns *s)
     const int rc = engines_append_potential(s, total, s->moved.data(), s->moved_val.data());
     s->moved_sent = total;
     return rc;
+}
+
+// Relabels the nodes so that id order = current thread order (root keeps id n).  Everything indexed by node is permuted, every arc's end
+// points are translated; arc ids, states, flows, costs stay where they are.  perm_out (optional) receives new id per CURRENT id.
+void renumber_nodes(mcf_ns *s, std::vector<int32_t> *perm_out)
+{
+    const int n = s->n, N = n + 1;
+    std::vector<int32_t> to(N);                      // current id -> new id
+    {
+        int u = s->nxt[s->root];
+        for (int k = 0; k < n; ++k) { to[u] = k; u = s->nxt[u]; }
+        to[s->root] = n;
+    }
+    auto permute = [&](auto &vec) {                 // in place: the engines have the potentials' storage bound (and registered with HIP)
+        using E = typename std::remove_reference<decltype(vec)>::type::value_type;
+        std::vector<E> tmp((size_t)N);
+        for (int u = 0; u < N; ++u) tmp[to[u]] = vec[u];
+        std::copy(tmp.begin(), tmp.end(), vec.begin());
+    };
+    auto translate = [&](auto &vec) { for (int u = 0; u < N; ++u) if (vec[u] >= 0) vec[u] = to[vec[u]]; };
+    permute(s->supply); permute(s->pi); permute(s->par); permute(s->par_arc); permute(s->nxt); permute(s->prv); permute(s->sub); permute(s->fin);
+    permute(s->par_dir); permute(s->follow);
+    translate(s->par); translate(s->nxt); translate(s->prv); translate(s->fin); translate(s->follow);
+    const size_t A = s->tail.size();
+    for (size_t e = 0; e < A; ++e) { s->tail[e] = to[s->tail[e]]; s->head[e] = to[s->head[e]]; }
+    if (s->new_of.empty()) {
+        s->new_of = to;
+    } else {
+        for (int v = 0; v < N; ++v) s->new_of[v] = to[s->new_of[v]];
+    }
+    s->orig_of.assign(N, 0);
+    for (int v = 0; v < N; ++v) s->orig_of[s->new_of[v]] = v;
+    // the pivot in progress (none between pivots, but keep the fields meaningful)
+    auto tr1 = [&](int &x) { if (x >= 0) x = to[x]; };
+    tr1(s->join); tr1(s->u_in); tr1(s->v_in); tr1(s->u_out); tr1(s->v_out);
+    s->walked_since_renumber = 0; s->jumps_since_renumber = 0; s->renumbers += 1;
+    if (perm_out) perm_out->swap(to);
+}
+
+// back to the caller's ids (end of a solve)
+void restore_node_ids(mcf_ns *s)
+{
+    if (s->new_of.empty()) return;
+    const int N = s->n + 1;
+    const std::vector<int32_t> &back = s->orig_of;      // id in use -> caller's id
+    auto permute = [&](auto &vec) {
+        using E = typename std::remove_reference<decltype(vec)>::type::value_type;
+        std::vector<E> tmp((size_t)N);
+        for (int u = 0; u < N; ++u) tmp[back[u]] = vec[u];
+        std::copy(tmp.begin(), tmp.end(), vec.begin());
+    };
+    auto translate = [&](auto &vec) { for (int u = 0; u < N; ++u) if (vec[u] >= 0) vec[u] = back[vec[u]]; };
+    permute(s->supply); permute(s->pi); permute(s->par); permute(s->par_arc); permute(s->nxt); permute(s->prv); permute(s->sub); permute(s->fin);
+    permute(s->par_dir); permute(s->follow);
+    translate(s->par); translate(s->nxt); translate(s->prv); translate(s->fin); translate(s->follow);
+    const size_t A = s->tail.size();
+    for (size_t e = 0; e < A; ++e) { s->tail[e] = back[s->tail[e]]; s->head[e] = back[s->head[e]]; }
+    s->new_of.clear(); s->orig_of.clear();
 }
 
 // One pivot with a given entering arc, in two halves.  pivot_front does what the next search depends on -- the cycle, the State[] writes and
@@ -764,6 +842,49 @@ int mcf_ns_apply_pivot(mcf_ns *s, int32_t arc, int32_t *unbounded)
     return MCF_OK;
 }
 
+// Measurement / test aid: `count` pivots with the given entering arcs applied back to back without an engine -- the sequential half alone
+// (cycle search, flows, subtree walk, tree surgery), with the walk aids of mcf_ns_solve (smaller side, node renumbering every `renumber_every`
+// walked nodes per node of the graph; 0 = never).  Phase times land in the metrics; ids are the caller's again when it returns.
+int mcf_ns_replay(mcf_ns *s, const int32_t *arcs, int64_t count, int32_t smaller_side, double renumber_every)
+{
+    if (!s || count < 0 || (count && !arcs)) return mcf::fail(MCF_ERR_INVALID, "mcf_ns_replay: bad arguments");
+    if (!s->transformed) return mcf::fail(MCF_ERR_STATE, "mcf_ns_begin has not been called");
+    const double t_start = mcf::now_ns(), tick_start = ticks();
+    double t_tree = 0, t_pot = 0, t_renum = 0;
+    s->shift_smaller_side = smaller_side != 0;
+    s->walked_since_renumber = 0;
+    int64_t it = 0, moved = 0;
+    for (; it < count; ++it) {
+        const int arc = arcs[it];
+        if (arc < 0 || arc >= s->search_arcs || s->state[arc] == MCF_STATE_TREE) { s->shift_smaller_side = false; return mcf::fail(MCF_ERR_INVALID, "pivot %lld: arc %d cannot enter", (long long)it, arc); }
+        if (pivot(s, arc, &t_tree, &t_pot)) { s->status = MCF_UNBOUNDED; break; }
+        moved += s->moved_n;
+        s->walked_since_renumber += s->moved_n;
+        if (renumber_every > 0 && (double)s->walked_since_renumber > renumber_every * (s->n + 1)) {
+            const double t0 = ticks();
+            renumber_nodes(s, nullptr);
+            t_renum += ticks() - t0;
+        }
+    }
+    s->shift_smaller_side = false;
+    const double t0 = ticks();
+    restore_node_ids(s);
+    {   // pi[root] back to 0 (the smaller-side walks let it drift)
+        const int64_t off = s->pi[s->root];
+        if (off != 0) for (int u = 0; u <= s->n; ++u) s->pi[u] -= off;
+    }
+    t_renum += ticks() - t0;
+    const double ns_per_tick = (mcf::now_ns() - t_start) / std::max(1.0, ticks() - tick_start);
+    s->metrics.iterations += it;
+    s->metrics.potential_nodes += moved;
+    s->metrics.tree_update_us = t_tree * ns_per_tick / 1e3;
+    s->metrics.potential_update_us = t_pot * ns_per_tick / 1e3;
+    s->metrics.setup_us = t_renum * ns_per_tick / 1e3;           // here: time spent renumbering
+    s->metrics.loop_us = (mcf::now_ns() - t_start) / 1e3;
+    s->metrics.reserved = (int32_t)s->renumbers;
+    return MCF_OK;
+}
+
 int mcf_ns_finish(mcf_ns *s, int32_t *status)
 {
     if (!s) return mcf::fail(MCF_ERR_INVALID, "null solver");
@@ -887,6 +1008,20 @@ int mcf_ns_prepare(mcf_ns *s)
         }
         s->reload_min_engines = all ? std::max<int32_t>(lo, kWalkHintMin) : 0;
     }
+    {
+        // node relabelling in thread order (renumber_nodes) needs every engine's consent; MCF_NS_RENUMBER=0 switches it off, =x sets the
+        // interval in walked nodes per node of the graph
+        bool all = !(getenv("MCF_NS_RENUMBER") && getenv("MCF_NS_RENUMBER")[0] == '0' && getenv("MCF_NS_RENUMBER")[1] == 0);
+        for (int r = 0; r < shards && all; ++r) {
+            int32_t yes = 0;
+            rc = mcf_engine_can_renumber(r == 0 ? s->engine : s->peers[r - 1], &yes);
+            if (rc) return rc;
+            all = yes != 0;
+        }
+        s->allow_renumber = all;
+        s->renumber_every = 128.0;
+        if (const char *u = getenv("MCF_NS_RENUMBER")) { const double v = atof(u); if (v > 0) s->renumber_every = v; }
+    }
     s->cands.assign((size_t)std::max(1, s->world), mcf_candidate{0, 0xFFFFFFFFu, -1, 0, 0xFFFFFFFFu, -1});
     if (s->shard_mode == mcf_ns::kHost) { rc = mcf_exchange_open(&s->exchange, s->exchange_name.c_str(), s->rank, s->world); if (rc) return rc; }
     s->metrics.config_flags = s->config.flags;
@@ -924,6 +1059,12 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     s->piece_ticks = 0;
     s->shift_smaller_side = s->allow_smaller_side;
     s->reload_min = s->reload_min_engines;
+    s->walked_since_renumber = 0;
+    s->renumber_ticks = 0;
+    s->dbg = mcf_ns::Debug{};
+    s->dbg.on = getenv("MCF_NS_DEBUG") != nullptr;
+    int dbg_class = -1;              // size class of the pivot whose search is being waited for
+    double dbg_t_prev = 0;
     // The search for pivot k+1 is posted as soon as the device has what it depends on (State[] writes, potentials); the rest of pivot k
     // (flows around the cycle, re-hanging the subtree) runs while the device is searching.  Engines sharded over RCCL search in one
     // blocking call (the all-gather runs on their stream), so for them the two halves simply follow each other.
@@ -932,12 +1073,24 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         const double t0 = ticks();
         int32_t found = 0, arc = -1;
         rc = engines_search_end(s, &found, &arc);
-        t_search += ticks() - t0;
+        const double t_got = ticks();
+        t_search += t_got - t0;
+        if (s->dbg.on && dbg_class >= 0) { s->dbg.wait[dbg_class] += t_got - t0; s->dbg.rest[dbg_class] += (t0 - dbg_t_prev); }
         if (rc || !found) break;
         if (s->trace && it < s->trace_cap) s->trace[it] = arc;
         ++it;
         if (it > max_iter) { s->status = MCF_INFEASIBLE; break; }                          // NS.cs:311-317
         if (s->pivot_limit && it > s->pivot_limit) { --it; limited = true; break; }
+        if (s->allow_renumber && (double)s->walked_since_renumber > s->renumber_every * (s->n + 1)) {
+            // no search in flight, nothing of a pivot half done: relabel the nodes in thread order, here and in the engines
+            const double tr0 = ticks();
+            std::vector<int32_t> perm;
+            renumber_nodes(s, &perm);
+            rc = engines_renumber(s, perm.data());
+            s->renumber_ticks += ticks() - tr0;
+            if (rc) break;
+        }
+        const double t_pot_before = t_pot;
         if (pivot_front(s, arc, &t_pot)) { s->status = MCF_UNBOUNDED; break; }
         const double t1 = ticks();
         rc = s->engine_rc;
@@ -953,14 +1106,22 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         if (rc) break;                     // the pivot stays half done: the solver is unusable after an engine error, but nothing is left running
         pivot_back(s, &t_tree);
         s->metrics.potential_nodes += (int64_t)s->moved_n;
-        { const int b = 31 - __builtin_clz((unsigned)std::max(s->moved_n, 1)); s->dbg_hist_n[b] += 1; s->dbg_hist_nodes[b] += s->moved_n;
-          if (2 * (int64_t)s->moved_n > s->n) { s->dbg_over_half += 1; s->dbg_over_half_nodes += s->moved_n; } }
+        s->walked_since_renumber += s->moved_n;
+        if (s->dbg.on) {
+            const int b = s->moved_n > 0 ? 31 - __builtin_clz((unsigned)s->moved_n) + 1 : 0;      // class 0: nothing moved; class b: 2^(b-1) .. 2^b - 1 nodes
+            dbg_class = b;
+            s->dbg.n[b] += 1; s->dbg.nodes[b] += s->moved_n;
+            s->dbg.walk[b] += (t_pot - t_pot_before);           // walk + hand-over + posting the search
+            dbg_t_prev = t_got + (t_pot - t_pot_before);        // what remains until the next wait begins is "rest" (cycle search, flows, tree)
+            if (2 * (int64_t)s->moved_n > s->n) { s->dbg.over_half += 1; s->dbg.over_half_nodes += s->moved_n; }
+        }
     }
     // ONE way out, error or not: no hand-over pending, no resident grid left spinning, trace length and iteration count filled in
     s->hand_over = false;
     s->shift_smaller_side = false;
     if (!rc) rc = normalise_potentials(s);
     s->reload_min = 0;
+    restore_node_ids(s);             // the caller's node ids again (the parked engines keep the relabelled ones: Solve() is single-shot)
     const char *first_error = rc ? mcf_last_error() : nullptr;
     std::string keep_error = first_error ? first_error : "";
     engines_park(s);                 // a resident scan grid must not outlive Solve()
@@ -972,15 +1133,25 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     s->metrics.pivot_search_us = t_search * ns_per_tick / 1e3;
     s->metrics.tree_update_us = t_tree * ns_per_tick / 1e3;
     s->metrics.potential_update_us = t_pot * ns_per_tick / 1e3;
-    if (getenv("MCF_NS_DEBUG") && it > 1000)
+    if (s->dbg.on && it > 1000)
         fprintf(stderr, "[ns] per pivot ns: search wait %.0f | walk %.0f | pieces handed over during walks %.0f | last hand-over %.0f | search begin %.0f | tree %.0f | everything else %.0f\n",
                 t_search * ns_per_tick / it, (t_pot - t_hand - t_begin - s->piece_ticks) * ns_per_tick / it, s->piece_ticks * ns_per_tick / it, t_hand * ns_per_tick / it, t_begin * ns_per_tick / it, t_tree * ns_per_tick / it,
                 ((ticks() - tick_start) - t_search - t_pot - t_tree) * ns_per_tick / it);
-    if (getenv("MCF_NS_DEBUG") && it > 1000) {
-        fprintf(stderr, "[ns] moved subtrees by size (pivots / nodes):");
-        for (int b = 0; b < 32; ++b) if (s->dbg_hist_n[b]) fprintf(stderr, " 2^%d: %lld / %lld |", b, (long long)s->dbg_hist_n[b], (long long)s->dbg_hist_nodes[b]);
-        fprintf(stderr, " more than half of the %d nodes: %lld / %lld | walks announced as a reload of _pi (%d nodes and more): %lld\n", s->n, (long long)s->dbg_over_half,
-                (long long)s->dbg_over_half_nodes, s->reload_min_engines, (long long)s->dbg_reload_walks);
+    if (s->dbg.on && it > 1000) {
+        fprintf(stderr, "[ns] pivots by size of the moved subtree: nodes | pivots | share of pivots | nodes moved | us per pivot: walk+hand-over, search wait, rest | share of the solve\n");
+        const double all_ticks = std::max(1.0, ticks() - tick_start);
+        for (int b = 0; b < 32; ++b) {
+            if (!s->dbg.n[b]) continue;
+            const double k = (double)s->dbg.n[b], us = ns_per_tick / 1e3;
+            char label[48];
+            if (b == 0) snprintf(label, sizeof(label), "0");
+            else if (b == 1) snprintf(label, sizeof(label), "1");
+            else snprintf(label, sizeof(label), "%d-%d", 1 << (b - 1), (1 << b) - 1);
+            fprintf(stderr, "[ns]   %14s | %8lld | %5.1f %% | %11lld | %7.2f %7.2f %7.2f | %5.1f %%\n", label, (long long)s->dbg.n[b], 100.0 * k / (double)it, (long long)s->dbg.nodes[b],
+                    s->dbg.walk[b] * us / k, s->dbg.wait[b] * us / k, s->dbg.rest[b] * us / k, 100.0 * (s->dbg.walk[b] + s->dbg.wait[b] + s->dbg.rest[b]) / all_ticks);
+        }
+        fprintf(stderr, "[ns] more than half of the %d nodes: %lld pivots / %lld nodes | walks announced as a reload of _pi (%d nodes and more): %lld | nodes relabelled in thread order %lld times, %.1f ms\n", s->n, (long long)s->dbg.over_half,
+                (long long)s->dbg.over_half_nodes, s->reload_min_engines, (long long)s->dbg.reload_walks, (long long)s->renumbers, s->renumber_ticks * ns_per_tick / 1e6);
     }
     mcf_engine_get_stats(s->engine, &s->metrics.engine);
     // the rest of SolverMetrics: NS.cs:262-270 (initial block size), :276 (expected iterations), :344-357

@@ -260,6 +260,11 @@ class NetworkSimplex:
     def finish(self) -> int:
         st = C.c_int32(); L.check(L.lib().mcf_ns_finish(self._h, C.byref(st))); return st.value
 
+    def replay(self, arcs, smaller_side=True, renumber_every=0.0):
+        """mcf_ns_replay: the given entering arcs applied back to back (no engine): the sequential half alone, timed in get_metrics()."""
+        arcs = _i32(arcs)
+        L.check(L.lib().mcf_ns_replay(self._h, arcs, arcs.shape[0], int(smaller_side), float(renumber_every))); return self
+
     def internal(self) -> dict:
         ms, cap = C.c_int32(), C.c_int32()
         ps, pt = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
@@ -407,6 +412,12 @@ class PivotEngine:
 
     def reload_potentials(self, changed_nodes: int):
         L.check(L.lib().mcf_engine_reload_potentials(self._h, changed_nodes))
+
+    def renumber_nodes(self, new_of):
+        """mcf_engine_renumber_nodes: new_of[old id] = new id (a permutation); a bound potential array must already be in the new order."""
+        new_of = _i32(new_of)
+        assert new_of.shape == (self.node_count,)
+        L.check(L.lib().mcf_engine_renumber_nodes(self._h, new_of))
 
     def patch_arcs(self, arcs, source, target, cost):
         arcs = _i32(arcs)

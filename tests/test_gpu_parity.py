@@ -1165,3 +1165,69 @@ def test_overlapping_potential_lists_between_two_searches(mode):
     f, e, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
     assert eng.find_entering() == (f, e, c)
     assert np.array_equal(eng.download_pi(), a["pi"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+def test_solve_with_nodes_relabelled_in_thread_order(mode, monkeypatch):
+    """mcf_ns_solve relabels the nodes in thread order every so often (renumber_nodes / mcf_engine_renumber_nodes) so that the host's walks run
+    through memory front to back.  Arc ids never change, so the pivots, flows and (after the ids are restored) potentials are the reference's.
+    Forced here to happen hundreds of times per solve, in every engine mode."""
+    rc_layout = isinstance(mode, str)
+    flags = _mode_flags(mode, monkeypatch)
+    monkeypatch.setenv("MCF_NS_RENUMBER", "0.05")
+    for name, cases in [("netgen_8_10a", [(O.SEM_CSHARP_OPT, O.RULE_BEST, 4), (O.SEM_CSHARP_OPT, O.RULE_BLOCK, 4), (O.SEM_CSHARP, O.RULE_BLOCK, 4), (O.SEM_CSHARP_OPT, O.RULE_FIRST, 4)]),
+                        ("AURV19V6", [(O.SEM_CSHARP_OPT, O.RULE_BEST, 4), (O.SEM_CSHARP_OPT, O.RULE_BLOCK, 0)])]:
+        p = load(name)
+        for sem, rule, vw in cases:
+            o, st_o, tr_o, ns, st = _solve_both(p, sem, rule, flags=flags, vw=vw)
+            assert st == st_o == O.OPTIMAL
+            assert np.array_equal(ns.trace(), tr_o), (name, sem, rule)
+            assert ns.get_total_cost() == o.total_cost and np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
+            m = ns.get_metrics()
+            assert m["engine"]["renumberings"] >= 5, (name, sem, rule, m["engine"]["renumberings"])
+            v = ns.validate()
+            assert v["valid"] == 1 and v["objective"] == v["dual_cost"] == o.total_cost
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bound", [False, True], ids=["mirror", "bound-potentials"])
+@pytest.mark.parametrize("mode", MODES)
+def test_raw_engine_follows_a_relabelling_of_its_nodes(mode, bound, monkeypatch):
+    """mcf_engine_renumber_nodes between searches, with patches queued before it (they go out under the old ids) and after it."""
+    flags = _mode_flags(mode, monkeypatch)
+    rng = np.random.default_rng(5)
+    for m_s, n in [(5003, 700), (400003, 100001)]:
+        a = _random_soa(rng, m_s, n, 50, 1000, extra=0)
+        eng = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible, flags=flags)
+        eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+        pi = a["pi"].copy()
+        if bound:
+            eng.bind_potentials(pi)
+        for it in range(8):
+            f, e, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+            assert eng.find_entering() == (f, e, c), (m_s, it)
+            arcs = rng.choice(m_s, 2, replace=False).astype(np.int32); vals = rng.integers(-1, 2, 2).astype(np.int8)
+            a["state"][arcs] = vals
+            eng.patch_state(arcs, vals)
+            k = int(rng.choice([1, 30, 700]))
+            nodes = rng.choice(n, size=min(k, n), replace=False).astype(np.int32)
+            sigma = int(rng.integers(-40, 41))
+            a["pi"][nodes] += sigma
+            if bound:
+                pi[nodes] += sigma
+                eng.shift_potential(nodes, pi[nodes], sigma)
+            else:
+                eng.update_potential(nodes, sigma)
+            if it % 2 == 1:
+                new_of = rng.permutation(n).astype(np.int32)
+                back = np.empty(n, np.int32); back[new_of] = np.arange(n, dtype=np.int32)
+                a["src"], a["tgt"] = new_of[a["src"]], new_of[a["tgt"]]
+                a["pi"] = a["pi"][back].copy()
+                if bound:
+                    pi[:] = pi[back]
+                eng.renumber_nodes(new_of)
+        assert np.array_equal(eng.download_pi(), a["pi"])
+        assert eng.stats()["renumberings"] == 4
+    with pytest.raises(M.McfError):
+        eng.renumber_nodes(np.zeros(n, np.int32))          # not a permutation
