@@ -212,7 +212,7 @@ struct mcf_engine {
     bool async_posted = false;                    // a refresh is on its way while the host keeps answering from the current list
     uint32_t async_at = 0, posted_at = 0;
     int patch_capacity = 0;                       // potential patches one request / one staged update can carry (2 * node_count + 256)
-    int cand_max_nodes = 96, cand_refresh_low = 12;
+    int cand_max_nodes = 256, cand_refresh_low = 12;      // sweep on config 3 (profiles/r03_cand_nodes_sweep.txt): 192-384 nodes evaluated on the host beat a device round trip
     // where the host's time goes in candidate mode (TSC ticks; printed by mcf_engine_destroy when MCF_HIP_CAND_DEBUG is set)
     double tk_absorb = 0, tk_decide = 0, tk_post = 0, tk_collect = 0, tk_probe = 0;
     int64_t n_sync_posts = 0, n_async_waits = 0, n_gap_pivots = 0, n_heap_push = 0, n_heap_pop = 0, n_list_skip = 0;

@@ -52,6 +52,7 @@ struct mcf_ns {
     std::vector<int32_t> new_of, orig_of;
     int64_t walked_since_renumber = 0, jumps_since_renumber = 0, renumbers = 0;
     bool allow_renumber = false;
+    bool seq_walk = true;             // after the first relabelling the big walks go in runs of consecutive ids (MCF_NS_SEQWALK=0: keep the hinted walk)
     double renumber_every = 128.0;    // relabel when the walks since the last relabelling covered this many times the node count
     double renumber_ticks = 0;
     int64_t sum_supply = 0, art_cost = 0;
@@ -438,6 +439,26 @@ void shift_potentials(mcf_ns *s)
         // the walk only moves the potentials.  The hints need the node kWalkAhead steps back: a ring of that many.
         int64_t *const pi = s->pi.data();
         const int32_t *const nxt = s->nxt.data();
+        if (s->renumbers > 0 && s->seq_walk) {
+            int i = 0, a = first;
+            int64_t jumps = 0;
+            while (i < count) {
+                int nx;
+                do {
+                    pi[a] += sigma;
+                    nx = nxt[a];
+                    ++i;
+                    if (nx != a + 1) { ++jumps; break; }
+                    ++a;
+                } while (i < count);
+                a = nx;
+            }
+            s->jumps_since_renumber += jumps;
+            s->moved_as_reload = true;
+            s->moved_sent = count;
+            if (s->dbg.on) s->dbg.reload_walks += 1;
+            return;
+        }
         int32_t *const follow = s->follow.data();
         int32_t ring[kWalkAhead];
         int a = first;
@@ -470,9 +491,39 @@ void shift_potentials(mcf_ns *s)
         if (lo == hi) { nodes[lo] = a; vals[lo] = (pi[a] += sigma); }
         return;
     }
+    const int piece = walk_piece();
+    if (s->renumbers > 0 && s->seq_walk) {
+        // After a relabelling in thread order the successor of node a is a + 1 almost everywhere: walk in RUNS.  Inside a run the next
+        // address does not depend on the loaded successor (the exit test is a predicted branch, not a data dependency), so the loads of
+        // consecutive nodes overlap and the hardware prefetcher sees a linear stream; a jump costs one unpredicted miss.
+        int i = 0, a = first;
+        int64_t jumps = 0;
+        while (i < count) {
+            const int stop = s->hand_over && count - (s->moved_sent + piece) >= piece / 2 ? std::max(i, s->moved_sent + piece) : count;
+            while (i < stop) {
+                int nx;
+                do {
+                    nodes[i] = a;
+                    vals[i] = (pi[a] += sigma);
+                    nx = nxt[a];
+                    ++i;
+                    if (nx != a + 1) { ++jumps; break; }
+                    ++a;
+                } while (i < stop);
+                a = nx;
+            }
+            if (i < count) {
+                const double tp = ticks();
+                if (!s->engine_rc) s->engine_rc = engines_append_potential(s, i - s->moved_sent, nodes + s->moved_sent, vals + s->moved_sent);
+                s->piece_ticks += ticks() - tp;
+                s->moved_sent = i;
+            }
+        }
+        s->jumps_since_renumber += jumps;
+        return;
+    }
     int32_t *const follow = s->follow.data();
     int a = first;
-    const int piece = walk_piece();
     // the first kWalkAhead nodes have no node that far behind them to leave a hint with (count >= kWalkHintMin > kWalkAhead)
     int i = 0;
     for (; i < kWalkAhead; ++i) {
@@ -1021,6 +1072,7 @@ int mcf_ns_prepare(mcf_ns *s)
         s->allow_renumber = all;
         s->renumber_every = 128.0;
         if (const char *u = getenv("MCF_NS_RENUMBER")) { const double v = atof(u); if (v > 0) s->renumber_every = v; }
+        s->seq_walk = !(getenv("MCF_NS_SEQWALK") && getenv("MCF_NS_SEQWALK")[0] == '0');
     }
     s->cands.assign((size_t)std::max(1, s->world), mcf_candidate{0, 0xFFFFFFFFu, -1, 0, 0xFFFFFFFFu, -1});
     if (s->shard_mode == mcf_ns::kHost) { rc = mcf_exchange_open(&s->exchange, s->exchange_name.c_str(), s->rank, s->world); if (rc) return rc; }
@@ -1150,8 +1202,8 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
             fprintf(stderr, "[ns]   %14s | %8lld | %5.1f %% | %11lld | %7.2f %7.2f %7.2f | %5.1f %%\n", label, (long long)s->dbg.n[b], 100.0 * k / (double)it, (long long)s->dbg.nodes[b],
                     s->dbg.walk[b] * us / k, s->dbg.wait[b] * us / k, s->dbg.rest[b] * us / k, 100.0 * (s->dbg.walk[b] + s->dbg.wait[b] + s->dbg.rest[b]) / all_ticks);
         }
-        fprintf(stderr, "[ns] more than half of the %d nodes: %lld pivots / %lld nodes | walks announced as a reload of _pi (%d nodes and more): %lld | nodes relabelled in thread order %lld times, %.1f ms\n", s->n, (long long)s->dbg.over_half,
-                (long long)s->dbg.over_half_nodes, s->reload_min_engines, (long long)s->dbg.reload_walks, (long long)s->renumbers, s->renumber_ticks * ns_per_tick / 1e6);
+        fprintf(stderr, "[ns] more than half of the %d nodes: %lld pivots / %lld nodes | walks announced as a reload of _pi (%d nodes and more): %lld | nodes relabelled in thread order %lld times, %.1f ms (%.1f %% of the steps since the last time left the id order)\n", s->n, (long long)s->dbg.over_half,
+                (long long)s->dbg.over_half_nodes, s->reload_min_engines, (long long)s->dbg.reload_walks, (long long)s->renumbers, s->renumber_ticks * ns_per_tick / 1e6, 100.0 * (double)s->jumps_since_renumber / std::max<double>(1.0, (double)s->walked_since_renumber));
     }
     mcf_engine_get_stats(s->engine, &s->metrics.engine);
     // the rest of SolverMetrics: NS.cs:262-270 (initial block size), :276 (expected iterations), :344-357
