@@ -304,6 +304,11 @@ typedef struct mcf_engine_stats {
     int64_t rc_recomputes;        /* RC layout: potential lists naming more than a sixteenth of the nodes, after which every reduced cost of the
                                      shard was computed again instead of shifting the listed nodes' arcs one by one */
     int64_t renumberings;         /* mcf_engine_renumber_nodes calls */
+    int64_t shift_grid;           /* 1: the candidate cache's grid is the one that is patched straight from the request (register-resident arcs
+                                     and potentials, 64-bit, at most 131072 nodes): a pivot's one big subtree travels as node ids + sigma */
+    int64_t shift_lists;          /* requests that carried such a list */
+    int64_t mirror_uploads;       /* times the potentials / states in device memory were written again from the host's mirrors (that grid only
+                                     reads them when it starts; the host writes them when it has left) */
 } mcf_engine_stats;
 MCF_API int mcf_engine_get_stats(mcf_engine *e, mcf_engine_stats *out);
 MCF_API int mcf_engine_reset_stats(mcf_engine *e);

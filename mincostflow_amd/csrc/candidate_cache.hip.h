@@ -63,7 +63,8 @@ inline int cand_note_nodes_blind(mcf_engine *e, int32_t count, const int32_t *no
     e->blind_count = e->pend_node.size();
     // a list refresh that has arrived meanwhile is taken in now, so that this list can start travelling
     if (e->async_posted && cand_records_ready(e, 0)) { const int rc = cand_collect(e, e->async_at); if (rc) return rc; }
-    resident_stream(e);
+    if (e->shift_grid) shift_stream(e);
+    else resident_stream(e);
     return MCF_OK;
 }
 
@@ -311,8 +312,174 @@ int cand_post_rc(mcf_engine *e)
     return MCF_OK;
 }
 
+// ---- the grid that is patched straight from the request (resident_cand_kernel; kernels.hip.h has the mailbox layout)
+
+// After that grid has left: the arrays in device memory are as the LAST LAUNCH found them.  The host's mirrors are authoritative in candidate
+// mode (potentials: the bound array or e->pi; states: h_state), so they are simply written again -- and with that the device has heard
+// everything: whatever was waiting to be told is dropped.
+int device_sync_from_mirrors(mcf_engine *e)
+{
+    const int64_t *pi = cand_pi(e);
+    HIP_TRY(hipMemcpyAsync(e->d_pi, pi, sizeof(int64_t) * (size_t)e->d.node_count, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_state, e->h_state.data() + e->begin, (size_t)(e->end - e->begin), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
+    e->pend_shift = false;
+    e->sync_nodes.clear(); e->sync_arcs.clear(); e->rc_sync.clear(); e->rc_shift_unknown = false;
+    e->blind_count = 0; e->blind_sets = 0;
+    e->shift_streamed = 0;
+    e->st.mirror_uploads += 1;
+    return MCF_OK;
+}
+
+// header (+ entry and shift lines when with_patches) of request `seq`; the value entries are pend_node / pend_val [val_lo, end), the shift
+// list pend_node [0, n_shift)
+void shift_post_request(mcf_engine *e, uint32_t seq, uint32_t cmd, size_t val_lo, size_t n_shift, int64_t sigma, bool with_patches)
+{
+    alignas(16) uint32_t line[16], line1[16];
+    const int n_val = with_patches ? (int)(e->pend_node.size() - val_lo) : 0, n_st = with_patches ? (int)e->pend_arc.size() : 0;
+    const int extra_val = n_val > 1 ? n_val - 1 : 0, extra_st = n_st > 2 ? n_st - 2 : 0, entries = extra_val + extra_st;
+    memset(line1, 0, sizeof(line1));
+    for (int l = 0, i = 0; i < entries; ++l) {
+        memset(line, 0, sizeof(line));
+        for (int k = 0; k < kMailboxPatchesPerLine && i < entries; ++k, ++i) {
+            if (i < extra_val) {
+                const uint64_t v = (uint64_t)e->pend_val[val_lo + i + 1];
+                line[3 * k] = (uint32_t)e->pend_node[val_lo + i + 1];
+                line[3 * k + 1] = (uint32_t)v;
+                line[3 * k + 2] = (uint32_t)(v >> 32);
+            } else {
+                const int j = i - extra_val + 2;
+                line[3 * k] = (uint32_t)e->pend_arc[j];
+                line[3 * k + 1] = (uint32_t)e->pend_state[j];
+            }
+        }
+        line[15] = seq;
+        if (l == 0) memcpy(line1, line, sizeof(line));
+        else mailbox_write_line(e->mailbox + kMailboxTail + 16 * (size_t)(l - 1), line);
+    }
+    if (with_patches) {
+        const int total = (int)((n_shift + kShiftNodesPerLine - 1) / kShiftNodesPerLine);
+        for (int l = e->shift_streamed; l < total; ++l) {
+            memset(line, 0, sizeof(line));
+            for (int k = 0; k < kShiftNodesPerLine && (size_t)l * kShiftNodesPerLine + k < n_shift; ++k) line[k] = (uint32_t)e->pend_node[(size_t)l * kShiftNodesPerLine + k];
+            line[15] = seq;
+            mailbox_write_line(e->mailbox + e->shift_base + 16 * (size_t)l, line);
+        }
+        e->shift_streamed = 0;
+    }
+    memset(line, 0, sizeof(line));
+    line[0] = seq;
+    line[1] = cmd;
+    line[2] = (uint32_t)n_val;
+    line[3] = with_patches ? (uint32_t)n_shift : 0u;
+    line[5] = (uint32_t)n_st;
+    for (int k = 0; k < n_st && k < 2; ++k) { line[6 + 2 * k] = (uint32_t)e->pend_arc[k]; line[7 + 2 * k] = (uint32_t)e->pend_state[k]; }
+    if (n_val > 0) {
+        const uint64_t v = (uint64_t)e->pend_val[val_lo];
+        line[10] = (uint32_t)e->pend_node[val_lo];
+        line[11] = (uint32_t)v;
+        line[12] = (uint32_t)(v >> 32);
+    }
+    line[13] = (uint32_t)(uint64_t)sigma;
+    line[14] = (uint32_t)((uint64_t)sigma >> 32);
+    line[15] = seq;
+    _mm_sfence();                                  // entry and shift lines leave the write-combining buffers before any header does
+    for (int r = 0; r < e->poll_replicas; ++r) {
+        uint32_t *unit = e->mailbox + (size_t)r * kReplicaStride;
+        if (entries > 0) mailbox_write_line(unit + 16, line1);
+        mailbox_write_line(unit, line);
+    }
+    _mm_sfence();
+}
+// a request without patches: quit, or a scan request put there again for a grid that has just been started with current arrays
+void shift_post(mcf_engine *e, uint32_t seq, uint32_t cmd, bool) { shift_post_request(e, seq, cmd, 0, 0, 0, false); }
+
+// the complete shift lines of this pivot's big list start travelling while the host is still walking the subtree (cmd 2: "shift lines
+// 0 .. L-1 of the coming scan request are in place": the grid sets their bits and goes back to polling)
+int shift_stream_min_lines()
+{
+    static const int v = [] { int x = 96; if (const char *u = getenv("MCF_HIP_SHIFT_STREAM_LINES")) { const int y = atoi(u); if (y >= 8 && y <= 65536) x = y; } return x; }();
+    return v;
+}
+void shift_stream(mcf_engine *e)
+{
+    if (e->async_posted || e->blind_epoch != e->cand_now || e->blind_sets > 1 || !e->pend_shift) return;
+    if (!e->resident_running || e->in_flight != mcf_engine::kNoSearch) return;
+    const int complete = (int)(e->blind_count / kShiftNodesPerLine);
+    if (complete - e->shift_streamed < shift_stream_min_lines() || complete > e->max_shift_lines) return;
+    uint32_t next_seq = e->seq + 1;
+    if (next_seq == 0) next_seq = 1;
+    alignas(16) uint32_t line[16];
+    for (int l = e->shift_streamed; l < complete; ++l) {
+        for (int k = 0; k < kShiftNodesPerLine; ++k) line[k] = (uint32_t)e->pend_node[(size_t)l * kShiftNodesPerLine + k];
+        line[15] = next_seq;
+        mailbox_write_line(e->mailbox + e->shift_base + 16 * (size_t)l, line);
+    }
+    e->stream_sub += 1;
+    if (e->stream_sub == 0) e->stream_sub = 1;
+    memset(line, 0, sizeof(line));
+    line[0] = next_seq;
+    line[1] = 2u;
+    line[3] = (uint32_t)complete;
+    line[4] = e->stream_sub;
+    line[15] = next_seq;
+    _mm_sfence();
+    for (int r = 0; r < e->poll_replicas; ++r) mailbox_write_line(e->mailbox + (size_t)r * kReplicaStride, line);
+    _mm_sfence();
+    e->shift_streamed = complete;
+    e->stream_lines = complete;                    // "a list is travelling": what the other paths test before they change their mind about it
+}
+
+// posts a device search on that grid: this pivot's one big list as a shift list when it qualifies, everything else the device has not heard
+// as {node, current value} entries; anything that does not fit the scheme stops the grid, which brings the device up to date wholesale
+int cand_post_shift(mcf_engine *e)
+{
+    if (!e->resident_running) {                     // (re)start first: a start after a stop finds the arrays current and nothing left to tell
+        const int rc = resident_start(e, e->seq);
+        if (rc) return rc;
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const size_t n_b = e->blind_count, n_s = e->sync_nodes.size();
+        const bool blind_current = n_b == 0 || (e->blind_epoch == e->cand_now && e->blind_sets <= 1);
+        const bool as_shift = n_b > 0 && blind_current && e->pend_shift && n_b <= (size_t)e->max_shift_lines * kShiftNodesPerLine;
+        const bool fits = (int64_t)(as_shift ? n_s : n_b + n_s) <= (int64_t)e->patch_capacity && (int64_t)e->sync_arcs.size() <= (int64_t)e->mailbox_max_st;
+        if ((!as_shift && e->shift_streamed > 0) || !fits) {
+            // lines of a list that is no shift list any more have travelled, or the request would not fit: bring the device up to date wholesale
+            int rc = resident_stop(e);              // device_sync_from_mirrors: nothing is left to tell
+            if (!rc) rc = resident_start(e, e->seq);
+            if (rc) return rc;
+            continue;
+        }
+        const int64_t *pi = cand_pi(e);
+        const size_t val_lo = as_shift ? n_b : 0;
+        if (!as_shift) for (size_t i = 0; i < n_b; ++i) e->pend_val[i] = pi[e->pend_node[i]];      // current values (a node named twice carries the same one)
+        e->pend_node.resize(n_b + n_s);
+        e->pend_val.resize(n_b + n_s);
+        for (size_t i = 0; i < n_s; ++i) { e->pend_node[n_b + i] = e->sync_nodes[i]; e->pend_val[n_b + i] = pi[e->sync_nodes[i]]; }
+        e->pend_arc.assign(e->sync_arcs.begin(), e->sync_arcs.end());
+        e->pend_state.resize(e->pend_arc.size());
+        for (size_t i = 0; i < e->pend_arc.size(); ++i) e->pend_state[i] = e->h_state[e->pend_arc[i]];
+        e->prev_seq = e->seq;
+        e->seq += 1;
+        if (e->seq == 0) e->seq = 1;
+        shift_post_request(e, e->seq, 0u, val_lo, as_shift ? n_b : 0, e->pend_sigma, true);
+        if (!e->pend_node.empty() || !e->pend_arc.empty()) e->st.inline_updates += 1;
+        if (as_shift) e->st.shift_lists += 1;
+        e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
+        e->sync_nodes.clear(); e->sync_arcs.clear();
+        e->blind_count = 0;
+        e->stream_lines = 0;
+        e->posted_at = e->cand_now;
+        e->st.arcs_scanned += e->end - e->begin;
+        return MCF_OK;
+    }
+    return mcf::fail(MCF_ERR_STATE, "cand_post_shift: the request does not fit an empty mailbox");
+}
+
 int cand_post(mcf_engine *e)
 {
+    if (e->shift_grid) return cand_post_shift(e);
     if (e->rc_mode) return cand_post_rc(e);
     if (int rcb = cand_build_patches(e)) return rcb;
     if ((int)e->pend_arc.size() > e->mailbox_max_st) {      // hundreds of pivots' worth of state writes: cannot happen between two requests, kept for safety

@@ -158,6 +158,12 @@ struct mcf_engine {
     // resident mode (flag MCF_ENGINE_RESIDENT): mailbox in BAR-mapped fine-grained VRAM, exit record in pinned host memory
     bool resident_ok = false, resident_running = false, resident_reg = false;
     bool has_slot = false;         // this engine's grid occupies one of the device's resident slots (resident_slot_acquire)
+    // the candidate cache's register-resident grid that is patched straight from the request (resident_cand_kernel): the one big subtree of
+    // a pivot travels as bare node ids + sigma, the arrays in memory are only read when the grid starts (and written by the host when it stops)
+    bool shift_grid = false;
+    uint32_t shift_base = 0;       // dword offset of the shift lines in the mailbox
+    int max_shift_lines = 0;
+    int shift_streamed = 0;        // shift lines of the coming request already in place (cmd 2 posts)
     // host-side phase times are counted in time-stamp-counter ticks (a clock call costs 20+ ns, four of them per search) and scaled to ns
     // in mcf_engine_get_stats against the wall clock since creation
     double wait_ticks = 0, launch_ticks = 0, cal_ns = 0, cal_ticks = 0;
@@ -956,14 +962,16 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
         if (want && !(desc->flags & (MCF_ENGINE_TIME_EVERY_KERNEL | MCF_ENGINE_NO_INLINE_UPDATE))) {
             e->mailbox_max_st = 4096;
             e->mailbox_lines = 2 + (e->patch_capacity + e->mailbox_max_st + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
+            e->max_shift_lines = (desc->node_count + kShiftNodesPerLine - 1) / kShiftNodesPerLine + 1;
+            e->shift_base = (uint32_t)kMailboxTail + 16u * (uint32_t)e->mailbox_lines;
             if (const char *u = getenv("MCF_HIP_POLL_REPLICAS")) { const int v = atoi(u); if (v >= 1 && v <= kMaxReplicas) e->poll_replicas = v; }
             if (const char *u = getenv("MCF_HIP_POLL_SLEEP")) { const int v = atoi(u); if (v >= 0 && v <= 64) e->poll_sleep = v; }
-            e->mailbox = alloc_bar_vram(desc->device, (size_t)kMailboxTail * 4 + (size_t)e->mailbox_lines * 64);
+            e->mailbox = alloc_bar_vram(desc->device, (size_t)kMailboxTail * 4 + ((size_t)e->mailbox_lines + e->max_shift_lines) * 64);
             if (e->mailbox && hipHostMalloc((void **)&e->h_exit, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
                 hipHostGetDevicePointer((void **)&e->d_exit, e->h_exit, 0) == hipSuccess &&
                 hipEventCreate(&e->res_start) == hipSuccess && hipEventCreate(&e->res_stop) == hipSuccess) {
                 alignas(16) uint32_t zero[16] = {0};
-                for (size_t l = 0; l < (size_t)kMailboxTail / 16 + e->mailbox_lines; ++l) mailbox_write_line(e->mailbox + 16 * l, zero);
+                for (size_t l = 0; l < (size_t)kMailboxTail / 16 + e->mailbox_lines + e->max_shift_lines; ++l) mailbox_write_line(e->mailbox + 16 * l, zero);
                 _mm_sfence();
                 e->resident_ok = true;
                 if (e->rc_mode) {
@@ -980,6 +988,8 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
                 e->cand_on = !(desc->flags & MCF_ENGINE_NO_CANDIDATES) && !(getenv("MCF_HIP_CANDIDATES") && getenv("MCF_HIP_CANDIDATES")[0] == '0') &&
                              (e->resident_reg || e->rc_mode) && desc->rule == MCF_RULE_BEST_ELIGIBLE && desc->node_count < (1 << 29) &&
                              2 * (int64_t)desc->search_arc_num <= (int64_t)kCandMaxAvgDegree * desc->node_count;
+                e->shift_grid = e->cand_on && e->resident_reg && !e->rc_mode && !e->lds_pi && e->res_threads <= kPiRegThreads && !e->no_pireg && desc->int_width == 64 &&
+                                desc->node_count <= kShiftBits && !(getenv("MCF_HIP_SHIFT_GRID") && getenv("MCF_HIP_SHIFT_GRID")[0] == '0');
             }
         }
     }
@@ -999,6 +1009,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
     e->st.bytes_per_scan = (int64_t)(desc->int_width == 64 ? 17 : 13) * count + (int64_t)w * desc->node_count;
     e->st.scan_bytes_read = e->rc_mode ? (int64_t)9 * count : e->st.bytes_per_scan;
     e->st.rc_layout = e->rc_mode ? 1 : 0;
+    e->st.shift_grid = e->shift_grid ? 1 : 0;
     e->st.initial_block_size = e->st.current_block_size = e->block_size;
     *out = e;
     return MCF_OK;
@@ -1221,10 +1232,10 @@ int mcf_engine_update_potential(mcf_engine *e, int32_t count, const int32_t *nod
             std::vector<int64_t> vals((size_t)count);
             for (int i = 0; i < count; ++i) vals[i] = (e->pi[nodes[i]] += sigma);
             const bool first = e->blind_count == 0;
+            e->pend_shift = first;            // one list with one shift (known before the list starts travelling)
+            e->pend_sigma = sigma;
             const int rcn = cand_note_nodes_blind(e, count, nodes, vals.data(), false);
             if (rcn) return rcn;
-            e->pend_shift = first;            // one list with one shift
-            e->pend_sigma = sigma;
         } else {
             for (int i = 0; i < count; ++i) { e->pi[nodes[i]] += sigma; cand_note_node(e, nodes[i], true, sigma); }
         }
@@ -1266,11 +1277,11 @@ int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes,
         if (!e->ext_pi) for (int i = 0; i < count; ++i) e->pi[nodes[i]] = values[i];      // bound potentials: the caller's array already holds them
         if (count > e->cand_max_nodes || e->pivot_overflow) {
             const bool first = e->blind_count == 0;
-            const int rcn = cand_note_nodes_blind(e, count, nodes, values, e->cand_appending);
-            if (rcn) return rcn;
-            // the big list has ONE shift when every piece of it came with the same announced shift
+            // the big list has ONE shift when every piece of it came with the same announced shift (decided before the piece starts travelling)
             e->pend_shift = e->call_shift_known && (first || (e->pend_shift && e->pend_sigma == e->call_shift));
             e->pend_sigma = e->call_shift;
+            const int rcn = cand_note_nodes_blind(e, count, nodes, values, e->cand_appending);
+            if (rcn) return rcn;
         }
         else for (int i = 0; i < count; ++i) cand_note_node(e, nodes[i], e->call_shift_known, e->call_shift);
         e->st.potential_nodes += count;
@@ -1709,6 +1720,7 @@ int mcf_engine_reset_stats(mcf_engine *e)
     e->st.comm_ranks = keep.comm_ranks;
     e->st.scan_bytes_read = keep.scan_bytes_read;
     e->st.rc_layout = keep.rc_layout;
+    e->st.shift_grid = keep.shift_grid;
     return MCF_OK;
 }
 
@@ -1807,6 +1819,7 @@ int mcf_engine_comm_init(mcf_engine *e, const uint8_t id[128], int32_t rank, int
     if (e->cand_on) {              // the candidate cache lives on the resident grid's answers: hand what it still holds to the device and switch it off
         if (int rcf = flush_pending(e)) return rcf;
         e->cand_on = false;
+        e->shift_grid = false;
         e->st.candidates = 0;
     }
     if (e->resident_ok) {

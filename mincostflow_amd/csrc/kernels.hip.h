@@ -978,6 +978,283 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the candidate cache's grid, register resident
+// resident_cand_kernel<T>: Best Eligible with candidates for instances whose arcs AND end-point potentials live in registers (the headline
+// workload).  What distinguishes it from resident_kernel<..., CAND, PIREG>: a request is applied to the registers straight from the request,
+// and nothing else is touched -- no store into the potential / state arrays in memory, no wait for such stores, no gather after them.
+//   * SHIFT LIST: the one big subtree a pivot moved, as bare node ids (15 per line) + the pivot's sigma (NS.cs:1187-1190: one sigma for
+//     the whole subtree).  Every workgroup sets the nodes' bits in an exact bitmap in LDS (one bit per node: node_count <= kShiftBits) and
+//     every thread adds sigma to those of its eight end points whose bit is set.  The lines travel while the host is still walking the
+//     subtree (cmd 2 posts: set bits, no answer); 4 bytes per node instead of 12, and the host never forms the values.
+//   * VALUE ENTRIES {node, value}: the nodes the host-side cache touched since the last request, with their final values (they override
+//     the shift: a value is read by the host when the request is built).  Few: compared directly; many: rounds of up to kCandRoundLines
+//     lines through a hash table in LDS (node -> value) that every thread probes for its eight end points.
+//   * STATE WRITES {arc, state}: compared against the thread's four arcs.
+// The arrays in memory are only read when the grid starts: the host, whose mirrors are authoritative in candidate mode, writes them again
+// before every launch (resident_start) -- so a grid that left on its idle timeout comes back with current values and the request it finds
+// waiting is re-posted without patches.
+constexpr int kShiftBits = 131072;                // nodes the exact bitmap covers (16 KB of LDS)
+constexpr int kShiftNodesPerLine = 15;
+constexpr int kCandLines = 512;                   // staging: line 0 + 511 lines (32 KB)
+constexpr int kCandRoundLines = 480;              // value-entry lines per hash round: 2400 entries in ...
+constexpr int kCandHash = 4096;                   // ... this many slots
+constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;
+constexpr int kCandCompare = 20;                  // value entries beyond the header's that are matched by direct comparison
+
+// Mailbox of this grid.  Poll unit (replicated): line 0 = header, line 1 = first entry line.
+//   line 0   [0] seq [1] cmd (0 scan, 1 quit, 2 shift lines in place) [2] n_val [3] scan: n_shift nodes / cmd 2: shift lines in place so far
+//            [4] cmd 2: post counter [5] n_st [6..9] state writes 0, 1 {arc, state} [10..12] value entry 0 {node, lo, hi} [13..14] sigma [15] seq
+//   entry lines (tail, from kMailboxTail): five {a, b, c} each: value entries 1.., then state writes 2..; [15] = seq
+//   shift lines (from shift_base): fifteen node ids each; [15] = seq of the scan request they belong to
+template <typename T>
+__global__ __launch_bounds__(kPiRegThreads) void resident_cand_kernel(const ResidentParams<T> p, const uint32_t shift_base, const int max_shift_lines)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lm[kCandLines * 16];
+    __shared__ uint32_t bitmap[kShiftBits / 32];
+    __shared__ uint32_t hkey[kCandHash];
+    __shared__ __attribute__((aligned(8))) int64_t hval[kCandHash];
+    __shared__ uint32_t s_timeout;
+    const int tid = threadIdx.x, nt = (int)blockDim.x;
+    const int my_i0 = blockIdx.x * nt * kArcsPerThread + tid * kArcsPerThread;
+    TileData<T> mine;
+    load_tile<T>(p.src, p.tgt, p.cost, p.state, my_i0, mine);
+    T ps[4], pt[4];
+    gather_tile<T>(mine, p.pi, ps, pt);
+    for (int i = tid; i < kShiftBits / 32; i += nt) bitmap[i] = 0u;
+    for (int i = tid; i < kCandHash; i += nt) hkey[i] = kHashEmpty;
+    __syncthreads();
+    uint32_t last = p.start_seq, served = 0, last_sub = 0, shifted_for = p.start_seq;
+    int shift_done = 0;                                   // shift lines of the coming scan request whose bits are set
+    bool bits_set = false;
+    uint64_t scan_ticks = 0;
+    uint64_t idle_since = __builtin_amdgcn_s_memrealtime();
+    const uint32_t *const my_unit = p.mailbox + (size_t)(blockIdx.x % p.poll_replicas) * kReplicaStride;
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    constexpr int kStage = 32;                            // dword offset of the staging area in lm: lines 0 and 1 keep the poll unit
+    constexpr int kChunk = kCandLines - 2;
+    // stages `count` lines starting at line `first` of the area at dword offset `area` into lm[kStage..]; true when every tag is `seq`
+    auto stage = [&](uint32_t area, int first, int count, uint32_t seq) -> bool {
+        for (int base = 0; base < count * 4; base += nt * 4) {
+            v4u x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                x[q] = v4u{0u, 0u, 0u, 0u};
+                const int c = base + q * nt + tid;
+                if (c < count * 4) {
+                    const uint32_t *src = p.mailbox + (area + (size_t)(first + (c >> 2)) * 16 + (c & 3) * 4);
+                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x[q]) : "v"(src) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])::"memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = base + q * nt + tid;
+                if (c < count * 4) *reinterpret_cast<v4u *>(lm + kStage + c * 4) = x[q];
+            }
+        }
+        __syncthreads();
+        int bad = 0;
+        for (int l = tid; l < count; l += nt) bad |= (lm[kStage + l * 16 + 15] != seq);
+        return __syncthreads_or(bad) == 0;
+    };
+    for (;;) {
+        if (tid < 64) {
+            v4u x = v4u{0u, 0u, 0u, 0u};
+            uint32_t flag;
+            for (;;) {
+                if (tid < 8) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x) : "v"(my_unit + tid * 4) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)::"memory");
+                const uint32_t seq0 = lane_u32(x[0], 0), tag0 = lane_u32(x[3], 3), cmd0 = lane_u32(x[1], 0), sub0 = lane_u32(x[0], 1);
+                if (seq0 != last && tag0 == seq0 && (cmd0 != 2u || sub0 != last_sub)) { flag = 1u; break; }
+                if (__builtin_amdgcn_s_memrealtime() - idle_since > p.idle_ticks) { flag = 2u; break; }
+                for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+            }
+            if (tid < 8) *reinterpret_cast<v4u *>(lm + tid * 4) = x;
+            if (tid == 0) s_timeout = flag;
+        }
+        __syncthreads();
+        const uint32_t seq = lm[0], cmd = lm[1], sub = lm[4];
+        int n_val = (int)lm[2], n_st = (int)lm[5];
+        n_val = n_val < 0 ? 0 : (n_val > p.max_pi ? p.max_pi : n_val);
+        n_st = n_st < 0 ? 0 : (n_st > p.max_st ? p.max_st : n_st);
+        const bool apply_only = cmd == 2u;
+        int n_shift = apply_only ? 0 : (int)lm[3];
+        n_shift = n_shift < 0 ? 0 : (n_shift > max_shift_lines * kShiftNodesPerLine ? max_shift_lines * kShiftNodesPerLine : n_shift);
+        int shift_lines = apply_only ? (int)lm[3] : (n_shift + kShiftNodesPerLine - 1) / kShiftNodesPerLine;
+        shift_lines = shift_lines < 0 ? 0 : (shift_lines > max_shift_lines ? max_shift_lines : shift_lines);
+        const int64_t sigma = (int64_t)(((uint64_t)lm[14] << 32) | lm[13]);
+        const bool timed_out = s_timeout == 2u;
+        const bool line1_staged = lm[31] == seq;
+        const int st_arc0 = (int)lm[6], st_arc1 = (int)lm[8];
+        const uint32_t st_val0 = lm[7], st_val1 = lm[9];
+        const uint32_t v0_node = lm[10];
+        const T v0 = (T)(int64_t)(((uint64_t)lm[12] << 32) | lm[11]);
+        if (timed_out) {
+            if (tid == 0 && blockIdx.x == 0) resident_exit(p.exit_word, 2u, served, scan_ticks);
+            return;
+        }
+        const uint64_t t_seen = blockIdx.x == 0 ? __builtin_amdgcn_s_memrealtime() : 0;
+        if (cmd == 1u) {
+            if (tid == 0 && blockIdx.x == 0) resident_exit(p.exit_word, 1u, served, scan_ticks);
+            return;
+        }
+        // ---- shift lines not seen yet: set the nodes' bits (idempotent: a retry after a torn line repeats nothing harmful)
+        bool torn = false;
+        for (int first = shift_done; first < shift_lines && !torn; first += kChunk) {
+            const int chunk = shift_lines - first < kChunk ? shift_lines - first : kChunk;
+            if (!stage(shift_base, first, chunk, seq)) { torn = true; break; }
+            // a scan request knows how many nodes its last line holds; posted lines are complete
+            const int nodes_here = apply_only ? chunk * kShiftNodesPerLine : (n_shift - first * kShiftNodesPerLine < chunk * kShiftNodesPerLine ? n_shift - first * kShiftNodesPerLine : chunk * kShiftNodesPerLine);
+            for (int i = tid; i < nodes_here; i += nt) {
+                const uint32_t u = lm[kStage + (i / kShiftNodesPerLine) * 16 + i % kShiftNodesPerLine];
+                if (u < (uint32_t)kShiftBits) atomicOr(&bitmap[u >> 5], 1u << (u & 31));
+            }
+            bits_set = true;
+            shift_done = first + chunk;
+            __syncthreads();
+        }
+        if (torn) continue;
+        if (apply_only) {
+            last_sub = sub;
+            idle_since = __builtin_amdgcn_s_memrealtime();
+            continue;
+        }
+        // ---- the shift: once per request, before the value entries (they are final values and override it)
+        if (n_shift > 0 && shifted_for != seq) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t a = (uint32_t)mine.s.v[j], b = (uint32_t)mine.t.v[j];
+                if ((bitmap[(a >> 5) & (kShiftBits / 32 - 1)] >> (a & 31)) & 1u) ps[j] = (T)((int64_t)ps[j] + sigma);
+                if ((bitmap[(b >> 5) & (kShiftBits / 32 - 1)] >> (b & 31)) & 1u) pt[j] = (T)((int64_t)pt[j] + sigma);
+            }
+            shifted_for = seq;
+        }
+        // ---- header entries
+        if (n_val > 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ps[j] = mine.s.v[j] == (int)v0_node ? v0 : ps[j]; pt[j] = mine.t.v[j] == (int)v0_node ? v0 : pt[j]; }
+        }
+        if (n_st > 0) { const int a = st_arc0 - p.base - my_i0; if ((unsigned)a < 4u) mine.st4 = (mine.st4 & ~(0xFFu << (8 * a))) | ((st_val0 & 0xFFu) << (8 * a)); }
+        if (n_st > 1) { const int a = st_arc1 - p.base - my_i0; if ((unsigned)a < 4u) mine.st4 = (mine.st4 & ~(0xFFu << (8 * a))) | ((st_val1 & 0xFFu) << (8 * a)); }
+        // ---- entry lines: value entries 1.., then state writes 2..
+        const int extra_val = n_val > 1 ? n_val - 1 : 0, extra_st = n_st > 2 ? n_st - 2 : 0, entries = extra_val + extra_st;
+        const int lines = (entries + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
+        if (lines == 1 && line1_staged) {
+            // everything came with the poll
+            for (int i = 0; i < entries; ++i) {
+                const uint32_t q0 = lm[16 + 3 * i], q1 = lm[16 + 3 * i + 1], q2 = lm[16 + 3 * i + 2];
+                if (i < extra_val) {
+                    const T v = (T)(int64_t)(((uint64_t)q2 << 32) | q1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { ps[j] = mine.s.v[j] == (int)q0 ? v : ps[j]; pt[j] = mine.t.v[j] == (int)q0 ? v : pt[j]; }
+                } else {
+                    const int a = (int)q0 - p.base - my_i0;
+                    if ((unsigned)a < 4u) mine.st4 = (mine.st4 & ~(0xFFu << (8 * a))) | ((q1 & 0xFFu) << (8 * a));
+                }
+            }
+        } else {
+            for (int first = 0; first < lines && !torn; first += kCandRoundLines) {
+                const int chunk = lines - first < kCandRoundLines ? lines - first : kCandRoundLines;
+                // line 1 sits in the poll unit, the others in the tail: entry line l (0-based) is tail line l - 1
+                bool ok = true;
+                {
+                    for (int base = 0; base < chunk * 4; base += nt * 4) {
+                        v4u x[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            x[q] = v4u{0u, 0u, 0u, 0u};
+                            const int c = base + q * nt + tid;
+                            if (c < chunk * 4) {
+                                const int line = first + (c >> 2);
+                                const uint32_t *src = line == 0 ? my_unit + 16 + (c & 3) * 4 : p.mailbox + (kMailboxTail + (size_t)(line - 1) * 16 + (c & 3) * 4);
+                                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x[q]) : "v"(src) : "memory");
+                            }
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])::"memory");
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c = base + q * nt + tid;
+                            if (c < chunk * 4) *reinterpret_cast<v4u *>(lm + kStage + c * 4) = x[q];
+                        }
+                    }
+                    __syncthreads();
+                    int bad = 0;
+                    for (int l = tid; l < chunk; l += nt) bad |= (lm[kStage + l * 16 + 15] != seq);
+                    ok = __syncthreads_or(bad) == 0;
+                }
+                if (!ok) { torn = true; break; }
+                const int i_lo = first * kMailboxPatchesPerLine;
+                const int i_hi = entries < i_lo + chunk * kMailboxPatchesPerLine ? entries : i_lo + chunk * kMailboxPatchesPerLine;
+                const int v_hi = i_hi < extra_val ? i_hi : extra_val;                   // value entries of this round: [i_lo, v_hi)
+                const int n_here = v_hi > i_lo ? v_hi - i_lo : 0;
+                if (n_here <= kCandCompare) {
+                    for (int i = i_lo; i < v_hi; ++i) {
+                        const int rel = i - i_lo;
+                        const uint32_t *q = lm + kStage + (rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
+                        const int node = (int)q[0];
+                        const T v = (T)(int64_t)(((uint64_t)q[2] << 32) | q[1]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { ps[j] = mine.s.v[j] == node ? v : ps[j]; pt[j] = mine.t.v[j] == node ? v : pt[j]; }
+                    }
+                } else {
+                    // hash round: insert (a node may come twice, with the same value: the first claim of the slot wins), probe, wipe
+                    for (int i = i_lo + tid; i < v_hi; i += nt) {
+                        const int rel = i - i_lo;
+                        const uint32_t *q = lm + kStage + (rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
+                        const uint32_t node = q[0];
+                        uint32_t h = (node * 2654435761u) >> 20;                        // 12 bits
+                        for (int step = 0; step < kCandHash; ++step) {
+                            const uint32_t old = atomicCAS(&hkey[h], kHashEmpty, node);
+                            if (old == kHashEmpty || old == node) { hval[h] = (int64_t)(((uint64_t)q[2] << 32) | q[1]); break; }
+                            h = (h + 1) & (kCandHash - 1);
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t node = (uint32_t)(j < 4 ? mine.s.v[j & 3] : mine.t.v[j & 3]);
+                        uint32_t h = (node * 2654435761u) >> 20;
+                        for (int step = 0; step < kCandHash; ++step) {
+                            const uint32_t k = hkey[h];
+                            if (k == kHashEmpty) break;
+                            if (k == node) { const T v = (T)hval[h]; if (j < 4) ps[j & 3] = v; else pt[j & 3] = v; break; }
+                            h = (h + 1) & (kCandHash - 1);
+                        }
+                    }
+                    __syncthreads();
+                    for (int i = tid; i < kCandHash; i += nt) hkey[i] = kHashEmpty;
+                }
+                if (extra_st > 0 && i_hi > extra_val) {                                 // state writes of this round against my four arcs
+                    const int s_lo = i_lo > extra_val ? i_lo : extra_val;
+                    for (int i = s_lo; i < i_hi; ++i) {
+                        const int rel = i - i_lo;
+                        const uint32_t *q = lm + kStage + (rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
+                        const int a = (int)q[0] - p.base - my_i0;
+                        if ((unsigned)a < 4u) mine.st4 = (mine.st4 & ~(0xFFu << (8 * a))) | ((q[1] & 0xFFu) << (8 * a));
+                    }
+                }
+                __syncthreads();                                                        // the round has been consumed before the next one lands in lm
+            }
+            if (torn) continue;                                                         // value patches are final values: repeating them is harmless; the shift is guarded
+        }
+        // ---- scan
+        int64_t c1, c2;
+        uint32_t p1, p2;
+        fold_tile_best2<T>(mine, ps, pt, p.base + my_i0, c1, p1, c2, p2);
+        publish_candidates(c1, p1, c2, p2, p.slots, seq);
+        if (bits_set) {
+            for (int i = tid; i < kShiftBits / 32; i += nt) bitmap[i] = 0u;
+            bits_set = false;
+        }
+        shift_done = 0;
+        last = seq;
+        served += 1;
+        idle_since = __builtin_amdgcn_s_memrealtime();
+        if (blockIdx.x == 0) scan_ticks += idle_since - t_seen;
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ resident grid over the RC layout
 // The RC layout's scan (scan_rc_kernel) still pays one dispatch per search (about 6.5 us + 3 us of host launch on a 3-15 us scan).  This grid
 // serves the searches through the same mailbox as resident_kernel:

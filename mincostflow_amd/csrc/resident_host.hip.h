@@ -69,7 +69,10 @@ void launch_resident_r(mcf_engine *e, const ResidentParams<T> &p)
     const dim3 grid(e->res_grid), block(e->res_threads);
     const bool lpi = e->lds_pi;
     if (e->cand_on) {     // candidates: Best Eligible, register-resident tiles only
-        if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, true, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+        if (e->shift_grid) {
+            if constexpr (sizeof(T) == 8) hipExtLaunchKernelGGL((resident_cand_kernel<T>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p, e->shift_base, e->max_shift_lines);
+        }
+        else if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, true, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
         else if (e->res_threads <= kPiRegThreads && !e->no_pireg)       // the end points' potentials stay in registers between the requests
             hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, false, true, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
         else hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, false, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
@@ -316,6 +319,9 @@ void resident_stream(mcf_engine *e)
 }
 
 int search_end(mcf_engine *e, Key *k);
+int device_sync_from_mirrors(mcf_engine *e);
+void shift_post(mcf_engine *e, uint32_t seq, uint32_t cmd, bool with_patches);
+void shift_stream(mcf_engine *e);
 int cand_collect(mcf_engine *e, uint32_t at);
 bool cand_records_ready(const mcf_engine *e, int g);
 int resident_stop(mcf_engine *e);
@@ -349,12 +355,14 @@ int resident_stop(mcf_engine *e)
     e->prev_seq = e->seq;
     e->seq += 1;
     if (e->seq == 0) e->seq = 1;
-    resident_post(e, e->seq, 1u, false);
+    if (e->shift_grid) shift_post(e, e->seq, 1u, false);
+    else resident_post(e, e->seq, 1u, false);
     HIP_TRY(hipStreamSynchronize(e->stream));       // bounded: the grid leaves on quit, or by itself after kResidentIdleTicks
     e->resident_running = false;
     e->stream_lines = 0;
     resident_harvest(e);
     resident_slot_release(e);
+    if (e->shift_grid) return device_sync_from_mirrors(e);
     return MCF_OK;
 }
 
@@ -365,6 +373,15 @@ int resident_restart(mcf_engine *e)
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->resident_running = false;
     resident_harvest(e);
+    if (e->shift_grid) {
+        // that grid's registers are gone and the arrays in memory are not what it had: write them again from the host's mirrors (they are
+        // at least as new as the request in flight, which is all a candidate list needs -- see cand_decide), and put the request there
+        // again WITHOUT patches, or the new grid would apply a shift the values already contain
+        e->stream_lines = 0;
+        const int rc = device_sync_from_mirrors(e);
+        if (rc) return rc;
+        shift_post(e, e->seq, 0u, false);
+    }
     return resident_start(e, e->prev_seq);
 }
 
