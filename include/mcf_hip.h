@@ -309,6 +309,8 @@ typedef struct mcf_engine_stats {
     int64_t shift_lists;          /* requests that carried such a list */
     int64_t mirror_uploads;       /* times the potentials / states in device memory were written again from the host's mirrors (that grid only
                                      reads them when it starts; the host writes them when it has left) */
+    double phase_shift_ns, phase_values_ns, phase_scan_ns;   /* that grid's requests on workgroup 0's clock: fetching shift lines + setting bits /
+                                     fetching and applying value entries and state writes / evaluating, reducing, publishing */
 } mcf_engine_stats;
 MCF_API int mcf_engine_get_stats(mcf_engine *e, mcf_engine_stats *out);
 MCF_API int mcf_engine_reset_stats(mcf_engine *e);

@@ -163,6 +163,7 @@ struct mcf_engine {
     bool shift_grid = false;
     uint32_t shift_base = 0;       // dword offset of the shift lines in the mailbox
     int max_shift_lines = 0;
+    int cand_tiles = 1;            // register tiles per thread of that grid
     int shift_streamed = 0;        // shift lines of the coming request already in place (cmd 2 posts)
     // host-side phase times are counted in time-stamp-counter ticks (a clock call costs 20+ ns, four of them per search) and scaled to ns
     // in mcf_engine_get_stats against the wall clock since creation
@@ -988,8 +989,16 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
                 e->cand_on = !(desc->flags & MCF_ENGINE_NO_CANDIDATES) && !(getenv("MCF_HIP_CANDIDATES") && getenv("MCF_HIP_CANDIDATES")[0] == '0') &&
                              (e->resident_reg || e->rc_mode) && desc->rule == MCF_RULE_BEST_ELIGIBLE && desc->node_count < (1 << 29) &&
                              2 * (int64_t)desc->search_arc_num <= (int64_t)kCandMaxAvgDegree * desc->node_count;
-                e->shift_grid = e->cand_on && e->resident_reg && !e->rc_mode && !e->lds_pi && e->res_threads <= kPiRegThreads && !e->no_pireg && desc->int_width == 64 &&
+                e->shift_grid = e->cand_on && e->resident_reg && !e->rc_mode && !e->lds_pi && !e->no_pireg && desc->int_width == 64 &&
                                 desc->node_count <= kShiftBits && !(getenv("MCF_HIP_SHIFT_GRID") && getenv("MCF_HIP_SHIFT_GRID")[0] == '0');
+                if (e->shift_grid) {
+                    // that grid keeps 2 or 4 tiles of four arcs per thread: at most 256 threads, one wave per SIMD
+                    const int64_t groups4 = ((int64_t)count + kArcsPerThread - 1) / kArcsPerThread;
+                    e->cand_tiles = groups4 <= (int64_t)2 * e->res_grid * kCandThreads ? 2 : 4;
+                    const int64_t t = std::max<int64_t>(64, ((groups4 + (int64_t)e->cand_tiles * e->res_grid - 1) / ((int64_t)e->cand_tiles * e->res_grid) + 63) / 64 * 64);
+                    if (t > kCandThreads) e->shift_grid = false;       // cannot happen: resident_reg caps the arcs at 1 M
+                    else e->res_threads = (int)t;
+                }
             }
         }
     }

@@ -999,41 +999,69 @@ constexpr int kCandLines = 512;                   // staging: line 0 + 511 lines
 constexpr int kCandRoundLines = 480;              // value-entry lines per hash round: 2400 entries in ...
 constexpr int kCandHash = 4096;                   // ... this many slots
 constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;
-constexpr int kCandCompare = 20;                  // value entries beyond the header's that are matched by direct comparison
+constexpr int kCandCompare = 3;                   // value entries beyond the header's that are matched by direct comparison (~40 instructions each)
 
 // Mailbox of this grid.  Poll unit (replicated): line 0 = header, line 1 = first entry line.
 //   line 0   [0] seq [1] cmd (0 scan, 1 quit, 2 shift lines in place) [2] n_val [3] scan: n_shift nodes / cmd 2: shift lines in place so far
 //            [4] cmd 2: post counter [5] n_st [6..9] state writes 0, 1 {arc, state} [10..12] value entry 0 {node, lo, hi} [13..14] sigma [15] seq
 //   entry lines (tail, from kMailboxTail): five {a, b, c} each: value entries 1.., then state writes 2..; [15] = seq
 //   shift lines (from shift_base): fifteen node ids each; [15] = seq of the scan request they belong to
-template <typename T>
-__global__ __launch_bounds__(kPiRegThreads) void resident_cand_kernel(const ResidentParams<T> p, const uint32_t shift_base, const int max_shift_lines)
+// TILES register tiles of four arcs per thread (tile t of a thread lies gridDim * blockDim * 4 arcs behind tile t - 1), at most kCandThreads
+// threads: four waves, one per SIMD of the CU.  A wave instruction takes four cycles and two waves on one SIMD take turns, so the reductions of
+// seven waves of 448 threads (one tile each) ran at half the rate of these four.
+constexpr int kCandThreads = 256;
+template <typename T, int TILES>
+__global__ __launch_bounds__(kCandThreads) void resident_cand_kernel(const ResidentParams<T> p, const uint32_t shift_base, const int max_shift_lines)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lm[kCandLines * 16];
     __shared__ uint32_t bitmap[kShiftBits / 32];
+    __shared__ uint32_t vmap[kShiftBits / 32];           // marks of the value entries of the round under way
     __shared__ uint32_t hkey[kCandHash];
     __shared__ __attribute__((aligned(8))) int64_t hval[kCandHash];
     __shared__ uint32_t s_timeout;
+    // state writes are POSTED to the thread that holds the arc: whoever reads an entry marks byte `slot` of the owner's word pair, and every
+    // thread looks at its own words once per request (a loop over the entries in every thread cost 60+ cycles per entry and thread)
+    __shared__ uint32_t sp_mask[TILES * kCandThreads], sp_val[TILES * kCandThreads];
     const int tid = threadIdx.x, nt = (int)blockDim.x;
-    const int my_i0 = blockIdx.x * nt * kArcsPerThread + tid * kArcsPerThread;
-    TileData<T> mine;
-    load_tile<T>(p.src, p.tgt, p.cost, p.state, my_i0, mine);
-    T ps[4], pt[4];
-    gather_tile<T>(mine, p.pi, ps, pt);
-    for (int i = tid; i < kShiftBits / 32; i += nt) bitmap[i] = 0u;
+    int my_i[TILES];
+    TileData<T> mine[TILES];
+    T ps[TILES][4], pt[TILES][4];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        my_i[t] = (t * (int)gridDim.x + (int)blockIdx.x) * nt * kArcsPerThread + tid * kArcsPerThread;
+        const int at = my_i[t] < p.count_padded ? my_i[t] : 0;          // behind the arrays: a tile of nothing (state 0 = never eligible)
+        load_tile<T>(p.src, p.tgt, p.cost, p.state, at, mine[t]);
+        if (my_i[t] >= p.count_padded) mine[t].st4 = 0u;
+        gather_tile<T>(mine[t], p.pi, ps[t], pt[t]);
+    }
+    for (int i = tid; i < kShiftBits / 32; i += nt) { bitmap[i] = 0u; vmap[i] = 0u; }
     for (int i = tid; i < kCandHash; i += nt) hkey[i] = kHashEmpty;
+    for (int i = tid; i < TILES * kCandThreads; i += nt) { sp_mask[i] = 0u; sp_val[i] = 0u; }
     __syncthreads();
+    auto post_state = [&](int arc, uint32_t val) {
+        const int local = arc - p.base;
+        if ((unsigned)local >= (unsigned)p.count_padded) return;
+        const int tile = local / (nt * kArcsPerThread), t = tile / (int)gridDim.x;
+        if (tile % (int)gridDim.x != (int)blockIdx.x || t >= TILES) return;
+        const int r = local % (nt * kArcsPerThread), owner = r / kArcsPerThread, slot = r % kArcsPerThread;
+        atomicOr(&sp_mask[t * kCandThreads + owner], 0xFFu << (8 * slot));
+        atomicOr(&sp_val[t * kCandThreads + owner], (val & 0xFFu) << (8 * slot));
+    };
     uint32_t last = p.start_seq, served = 0, last_sub = 0, shifted_for = p.start_seq;
     int shift_done = 0;                                   // shift lines of the coming scan request whose bits are set
     bool bits_set = false;
     uint64_t scan_ticks = 0;
+    uint64_t ph_shift = 0, ph_values = 0, ph_scan = 0, n_shift_req = 0;       // workgroup 0's clock by phase (exit record words 4..11)
+    const uint64_t born_rt = __builtin_amdgcn_s_memrealtime(), born_clk = __builtin_amdgcn_s_memtime();
     uint64_t idle_since = __builtin_amdgcn_s_memrealtime();
     const uint32_t *const my_unit = p.mailbox + (size_t)(blockIdx.x % p.poll_replicas) * kReplicaStride;
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     constexpr int kStage = 32;                            // dword offset of the staging area in lm: lines 0 and 1 keep the poll unit
     constexpr int kChunk = kCandLines - 2;
-    // stages `count` lines starting at line `first` of the area at dword offset `area` into lm[kStage..]; true when every tag is `seq`
-    auto stage = [&](uint32_t area, int first, int count, uint32_t seq) -> bool {
+    // stages n_a shift lines (from shift line first_a) followed by n_v entry lines (from entry line first_v; entry line 0 sits in the poll
+    // unit, the others in the tail) into lm[kStage..] with ONE round of loads; true when every line carries the tag `seq`
+    auto fetch = [&](int n_a, int first_a, int n_v, int first_v, uint32_t seq) -> bool {
+        const int count = n_a + n_v;
         for (int base = 0; base < count * 4; base += nt * 4) {
             v4u x[4];
 #pragma unroll
@@ -1041,7 +1069,13 @@ __global__ __launch_bounds__(kPiRegThreads) void resident_cand_kernel(const Resi
                 x[q] = v4u{0u, 0u, 0u, 0u};
                 const int c = base + q * nt + tid;
                 if (c < count * 4) {
-                    const uint32_t *src = p.mailbox + (area + (size_t)(first + (c >> 2)) * 16 + (c & 3) * 4);
+                    const int l = c >> 2;
+                    const uint32_t *src;
+                    if (l < n_a) src = p.mailbox + (shift_base + (size_t)(first_a + l) * 16 + (c & 3) * 4);
+                    else {
+                        const int v = first_v + l - n_a;
+                        src = v == 0 ? my_unit + 16 + (c & 3) * 4 : p.mailbox + (kMailboxTail + (size_t)(v - 1) * 16 + (c & 3) * 4);
+                    }
                     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x[q]) : "v"(src) : "memory");
                 }
             }
@@ -1089,158 +1123,233 @@ __global__ __launch_bounds__(kPiRegThreads) void resident_cand_kernel(const Resi
         const uint32_t st_val0 = lm[7], st_val1 = lm[9];
         const uint32_t v0_node = lm[10];
         const T v0 = (T)(int64_t)(((uint64_t)lm[12] << 32) | lm[11]);
-        if (timed_out) {
-            if (tid == 0 && blockIdx.x == 0) resident_exit(p.exit_word, 2u, served, scan_ticks);
+        if (timed_out || cmd == 1u) {
+            if (tid == 0 && blockIdx.x == 0) {
+                // shader clock over this launch in MHz (s_memtime counts shader cycles, s_memrealtime 100 MHz): word 10
+                const uint64_t d_rt = __builtin_amdgcn_s_memrealtime() - born_rt, d_clk = __builtin_amdgcn_s_memtime() - born_clk;
+                n_shift_req = d_rt ? d_clk * 100 / d_rt : 0;
+                const uint64_t ph[4] = {ph_shift, ph_values, ph_scan, n_shift_req};
+                for (int q = 0; q < 4; ++q) {
+                    __hip_atomic_store(p.exit_word + 4 + 2 * q, (uint32_t)ph[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(p.exit_word + 5 + 2 * q, (uint32_t)(ph[q] >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                resident_exit(p.exit_word, timed_out ? 2u : 1u, served, scan_ticks);
+            }
             return;
         }
         const uint64_t t_seen = blockIdx.x == 0 ? __builtin_amdgcn_s_memrealtime() : 0;
-        if (cmd == 1u) {
-            if (tid == 0 && blockIdx.x == 0) resident_exit(p.exit_word, 1u, served, scan_ticks);
-            return;
-        }
-        // ---- shift lines not seen yet: set the nodes' bits (idempotent: a retry after a torn line repeats nothing harmful)
-        bool torn = false;
-        for (int first = shift_done; first < shift_lines && !torn; first += kChunk) {
-            const int chunk = shift_lines - first < kChunk ? shift_lines - first : kChunk;
-            if (!stage(shift_base, first, chunk, seq)) { torn = true; break; }
-            // a scan request knows how many nodes its last line holds; posted lines are complete
-            const int nodes_here = apply_only ? chunk * kShiftNodesPerLine : (n_shift - first * kShiftNodesPerLine < chunk * kShiftNodesPerLine ? n_shift - first * kShiftNodesPerLine : chunk * kShiftNodesPerLine);
-            for (int i = tid; i < nodes_here; i += nt) {
-                const uint32_t u = lm[kStage + (i / kShiftNodesPerLine) * 16 + i % kShiftNodesPerLine];
-                if (u < (uint32_t)kShiftBits) atomicOr(&bitmap[u >> 5], 1u << (u & 31));
-            }
-            bits_set = true;
-            shift_done = first + chunk;
-            __syncthreads();
-        }
-        if (torn) continue;
-        if (apply_only) {
-            last_sub = sub;
-            idle_since = __builtin_amdgcn_s_memrealtime();
-            continue;
-        }
-        // ---- the shift: once per request, before the value entries (they are final values and override it)
-        if (n_shift > 0 && shifted_for != seq) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t a = (uint32_t)mine.s.v[j], b = (uint32_t)mine.t.v[j];
-                if ((bitmap[(a >> 5) & (kShiftBits / 32 - 1)] >> (a & 31)) & 1u) ps[j] = (T)((int64_t)ps[j] + sigma);
-                if ((bitmap[(b >> 5) & (kShiftBits / 32 - 1)] >> (b & 31)) & 1u) pt[j] = (T)((int64_t)pt[j] + sigma);
-            }
-            shifted_for = seq;
-        }
-        // ---- header entries
-        if (n_val > 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { ps[j] = mine.s.v[j] == (int)v0_node ? v0 : ps[j]; pt[j] = mine.t.v[j] == (int)v0_node ? v0 : pt[j]; }
-        }
-        if (n_st > 0) { const int a = st_arc0 - p.base - my_i0; if ((unsigned)a < 4u) mine.st4 = (mine.st4 & ~(0xFFu << (8 * a))) | ((st_val0 & 0xFFu) << (8 * a)); }
-        if (n_st > 1) { const int a = st_arc1 - p.base - my_i0; if ((unsigned)a < 4u) mine.st4 = (mine.st4 & ~(0xFFu << (8 * a))) | ((st_val1 & 0xFFu) << (8 * a)); }
-        // ---- entry lines: value entries 1.., then state writes 2..
-        const int extra_val = n_val > 1 ? n_val - 1 : 0, extra_st = n_st > 2 ? n_st - 2 : 0, entries = extra_val + extra_st;
+        // ---- what has to be fetched: shift lines not seen yet, entry lines (value entries 1.., then state writes 2..) unless the one line
+        // there is came with the poll
+        const int extra_val = n_val > 1 ? n_val - 1 : 0, extra_st = n_st > 2 ? n_st - 2 : 0, entries = apply_only ? 0 : extra_val + extra_st;
         const int lines = (entries + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
-        if (lines == 1 && line1_staged) {
-            // everything came with the poll
-            for (int i = 0; i < entries; ++i) {
-                const uint32_t q0 = lm[16 + 3 * i], q1 = lm[16 + 3 * i + 1], q2 = lm[16 + 3 * i + 2];
-                if (i < extra_val) {
-                    const T v = (T)(int64_t)(((uint64_t)q2 << 32) | q1);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { ps[j] = mine.s.v[j] == (int)q0 ? v : ps[j]; pt[j] = mine.t.v[j] == (int)q0 ? v : pt[j]; }
-                } else {
-                    const int a = (int)q0 - p.base - my_i0;
-                    if ((unsigned)a < 4u) mine.st4 = (mine.st4 & ~(0xFFu << (8 * a))) | ((q1 & 0xFFu) << (8 * a));
+        const bool inline_entries = lines == 1 && line1_staged;
+        const int need_v = inline_entries ? 0 : lines;
+        // the nodes of `chunk` staged shift lines (staged from lm line `off`; `first` = index of the first of them in the list): set their bits
+        auto set_bits = [&](int off, int first, int chunk) {
+            const int left = n_shift - first * kShiftNodesPerLine;
+            const int nodes_here = apply_only ? chunk * kShiftNodesPerLine : (left < chunk * kShiftNodesPerLine ? left : chunk * kShiftNodesPerLine);
+            // A subtree's nodes come as runs of consecutive ids (the host relabels the nodes in thread order), and 32 consecutive ids share a
+            // word of the bitmap: neighbouring lanes take entries 37 apart so that one atomic instruction does not hit one word 32 times
+            int p2 = 64;
+            while (p2 < nodes_here) p2 <<= 1;
+            for (int x = tid; x < p2; x += nt) {
+                const int i = (x * 37) & (p2 - 1);
+                if (i < nodes_here) {
+                    const uint32_t u = lm[kStage + (off + i / kShiftNodesPerLine) * 16 + i % kShiftNodesPerLine];
+                    if (u < (uint32_t)kShiftBits) atomicOr(&bitmap[u >> 5], 1u << (u & 31));
                 }
             }
-        } else {
-            for (int first = 0; first < lines && !torn; first += kCandRoundLines) {
-                const int chunk = lines - first < kCandRoundLines ? lines - first : kCandRoundLines;
-                // line 1 sits in the poll unit, the others in the tail: entry line l (0-based) is tail line l - 1
-                bool ok = true;
-                {
-                    for (int base = 0; base < chunk * 4; base += nt * 4) {
-                        v4u x[4];
+        };
+        // the shift: once per request (a retry after a torn line must not repeat it), before the value entries, which override it
+        auto shift_once = [&]() {
+            if (n_shift > 0 && shifted_for != seq) {
+                // all the words first (independent LDS reads, one wait), then the adds as selects: with one wave per SIMD nothing hides a
+                // dependent LDS round trip (64 cycles each)
+                uint32_t wa[TILES][4], wb[TILES][4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            x[q] = v4u{0u, 0u, 0u, 0u};
-                            const int c = base + q * nt + tid;
-                            if (c < chunk * 4) {
-                                const int line = first + (c >> 2);
-                                const uint32_t *src = line == 0 ? my_unit + 16 + (c & 3) * 4 : p.mailbox + (kMailboxTail + (size_t)(line - 1) * 16 + (c & 3) * 4);
-                                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x[q]) : "v"(src) : "memory");
-                            }
-                        }
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])::"memory");
+                for (int t = 0; t < TILES; ++t)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int c = base + q * nt + tid;
-                            if (c < chunk * 4) *reinterpret_cast<v4u *>(lm + kStage + c * 4) = x[q];
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        wa[t][j] = bitmap[((uint32_t)mine[t].s.v[j] >> 5) & (kShiftBits / 32 - 1)];
+                        wb[t][j] = bitmap[((uint32_t)mine[t].t.v[j] >> 5) & (kShiftBits / 32 - 1)];
                     }
-                    __syncthreads();
-                    int bad = 0;
-                    for (int l = tid; l < chunk; l += nt) bad |= (lm[kStage + l * 16 + 15] != seq);
-                    ok = __syncthreads_or(bad) == 0;
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t da = ((wa[t][j] >> ((uint32_t)mine[t].s.v[j] & 31)) & 1u) ? sigma : 0;
+                        const int64_t db = ((wb[t][j] >> ((uint32_t)mine[t].t.v[j] & 31)) & 1u) ? sigma : 0;
+                        ps[t][j] = (T)((int64_t)ps[t][j] + da);
+                        pt[t][j] = (T)((int64_t)pt[t][j] + db);
+                    }
+                shifted_for = seq;
+            }
+            if (n_val > 0) {
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { ps[t][j] = mine[t].s.v[j] == (int)v0_node ? v0 : ps[t][j]; pt[t][j] = mine[t].t.v[j] == (int)v0_node ? v0 : pt[t][j]; }
+            }
+            if (tid == 0 && n_st > 0) post_state(st_arc0, st_val0);
+            if (tid == 1 && n_st > 1) post_state(st_arc1, st_val1);
+        };
+        // `chunk` entry lines starting with entry line `first`, found at dword offset `at` of lm: value entries into the registers (few:
+        // compared directly; many: through the hash table), state writes against my four arcs
+        auto apply_entries = [&](const uint32_t *at, int first, int chunk) {
+            const int i_lo = first * kMailboxPatchesPerLine;
+            const int i_hi = entries < i_lo + chunk * kMailboxPatchesPerLine ? entries : i_lo + chunk * kMailboxPatchesPerLine;
+            const int v_hi = i_hi < extra_val ? i_hi : extra_val;                       // value entries here: [i_lo, v_hi)
+            const int n_here = v_hi > i_lo ? v_hi - i_lo : 0;
+            if (n_here <= kCandCompare) {
+                for (int i = i_lo; i < v_hi; ++i) {
+                    const int rel = i - i_lo;
+                    const uint32_t *q = at + (rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
+                    const int node = (int)q[0];
+                    const T v = (T)(int64_t)(((uint64_t)q[2] << 32) | q[1]);
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { ps[t][j] = mine[t].s.v[j] == node ? v : ps[t][j]; pt[t][j] = mine[t].t.v[j] == node ? v : pt[t][j]; }
                 }
-                if (!ok) { torn = true; break; }
-                const int i_lo = first * kMailboxPatchesPerLine;
-                const int i_hi = entries < i_lo + chunk * kMailboxPatchesPerLine ? entries : i_lo + chunk * kMailboxPatchesPerLine;
-                const int v_hi = i_hi < extra_val ? i_hi : extra_val;                   // value entries of this round: [i_lo, v_hi)
-                const int n_here = v_hi > i_lo ? v_hi - i_lo : 0;
-                if (n_here <= kCandCompare) {
-                    for (int i = i_lo; i < v_hi; ++i) {
-                        const int rel = i - i_lo;
-                        const uint32_t *q = lm + kStage + (rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
-                        const int node = (int)q[0];
-                        const T v = (T)(int64_t)(((uint64_t)q[2] << 32) | q[1]);
+            } else {
+                // Many entries: every entry is inserted by one thread into a hash table (node -> value; a node may come twice, with the same
+                // value: the first claim of the slot wins) and marked in a second exact bitmap; a thread then tests its eight end points
+                // against the bitmap (one LDS read each) and probes the table only for the few that are marked.  A wave instruction costs four
+                // cycles here, so what counts is instructions per thread: comparing 20 entries against 8 end points directly is ~800 of them.
+                int p2 = 64;
+                while (p2 < n_here) p2 <<= 1;
+                for (int x = tid; x < p2; x += nt) {
+                    const int rel = (x * 37) & (p2 - 1);                                // neighbouring lanes: entries 37 apart (see set_bits)
+                    if (rel >= n_here) continue;
+                    const uint32_t *q = at + (rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
+                    const uint32_t node = q[0];
+                    atomicOr(&vmap[(node >> 5) & (kShiftBits / 32 - 1)], 1u << (node & 31));
+                    uint32_t h = (node * 2654435761u) >> 20;                            // 12 bits
+                    for (int step = 0; step < kCandHash; ++step) {
+                        const uint32_t old = atomicCAS(&hkey[h], kHashEmpty, node);
+                        if (old == kHashEmpty || old == node) { hval[h] = (int64_t)(((uint64_t)q[2] << 32) | q[1]); break; }
+                        h = (h + 1) & (kCandHash - 1);
+                    }
+                }
+                __syncthreads();
+                uint32_t marks = 0;                                                     // which of my end points are marked: all words first, one wait
+                {
+                    uint32_t w[TILES][8];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { ps[j] = mine.s.v[j] == node ? v : ps[j]; pt[j] = mine.t.v[j] == node ? v : pt[j]; }
-                    }
-                } else {
-                    // hash round: insert (a node may come twice, with the same value: the first claim of the slot wins), probe, wipe
-                    for (int i = i_lo + tid; i < v_hi; i += nt) {
-                        const int rel = i - i_lo;
-                        const uint32_t *q = lm + kStage + (rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
-                        const uint32_t node = q[0];
-                        uint32_t h = (node * 2654435761u) >> 20;                        // 12 bits
-                        for (int step = 0; step < kCandHash; ++step) {
-                            const uint32_t old = atomicCAS(&hkey[h], kHashEmpty, node);
-                            if (old == kHashEmpty || old == node) { hval[h] = (int64_t)(((uint64_t)q[2] << 32) | q[1]); break; }
-                            h = (h + 1) & (kCandHash - 1);
-                        }
-                    }
-                    __syncthreads();
+                    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) w[t][j] = vmap[((uint32_t)(j < 4 ? mine[t].s.v[j & 3] : mine[t].t.v[j & 3]) >> 5) & (kShiftBits / 32 - 1)];
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) marks |= ((w[t][j] >> ((uint32_t)(j < 4 ? mine[t].s.v[j & 3] : mine[t].t.v[j & 3]) & 31)) & 1u) << (8 * t + j);
+                }
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const uint32_t node = (uint32_t)(j < 4 ? mine.s.v[j & 3] : mine.t.v[j & 3]);
-                        uint32_t h = (node * 2654435761u) >> 20;
-                        for (int step = 0; step < kCandHash; ++step) {
-                            const uint32_t k = hkey[h];
-                            if (k == kHashEmpty) break;
-                            if (k == node) { const T v = (T)hval[h]; if (j < 4) ps[j & 3] = v; else pt[j & 3] = v; break; }
-                            h = (h + 1) & (kCandHash - 1);
+                        const uint32_t node = (uint32_t)(j < 4 ? mine[t].s.v[j & 3] : mine[t].t.v[j & 3]);
+                        if ((marks >> (8 * t + j)) & 1u) {
+                            uint32_t h = (node * 2654435761u) >> 20;
+                            for (int step = 0; step < kCandHash; ++step) {
+                                const uint32_t k = hkey[h];
+                                if (k == kHashEmpty) break;
+                                if (k == node) { const T v = (T)hval[h]; if (j < 4) ps[t][j & 3] = v; else pt[t][j & 3] = v; break; }
+                                h = (h + 1) & (kCandHash - 1);
+                            }
                         }
                     }
-                    __syncthreads();
-                    for (int i = tid; i < kCandHash; i += nt) hkey[i] = kHashEmpty;
+                __syncthreads();
+                // wipe: the marks by walking the entries again (whole words: no atomics needed, everybody writes 0), the table wholesale
+                for (int i = i_lo + tid; i < v_hi; i += nt) {
+                    const int rel = i - i_lo;
+                    const uint32_t node = at[(rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine)];
+                    vmap[(node >> 5) & (kShiftBits / 32 - 1)] = 0u;
                 }
-                if (extra_st > 0 && i_hi > extra_val) {                                 // state writes of this round against my four arcs
-                    const int s_lo = i_lo > extra_val ? i_lo : extra_val;
-                    for (int i = s_lo; i < i_hi; ++i) {
-                        const int rel = i - i_lo;
-                        const uint32_t *q = lm + kStage + (rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
-                        const int a = (int)q[0] - p.base - my_i0;
-                        if ((unsigned)a < 4u) mine.st4 = (mine.st4 & ~(0xFFu << (8 * a))) | ((q[1] & 0xFFu) << (8 * a));
-                    }
-                }
-                __syncthreads();                                                        // the round has been consumed before the next one lands in lm
+                for (int i = tid; i < kCandHash; i += nt) hkey[i] = kHashEmpty;
             }
-            if (torn) continue;                                                         // value patches are final values: repeating them is harmless; the shift is guarded
+            if (extra_st > 0 && i_hi > extra_val) {
+                const int s_lo = i_lo > extra_val ? i_lo : extra_val;
+                for (int i = s_lo + tid; i < i_hi; i += nt) {
+                    const int rel = i - i_lo;
+                    const uint32_t *q = at + (rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
+                    post_state((int)q[0], q[1]);
+                }
+            }
+        };
+        bool torn = false;
+        uint64_t t_shifted = 0;
+        const int pend_a = shift_lines - shift_done;
+        if (!apply_only && pend_a + need_v <= kChunk && need_v <= kCandRoundLines) {
+            // the usual case: everything this request still needs arrives with ONE round of loads
+            if (pend_a + need_v > 0) {
+                if (!fetch(pend_a, shift_done, need_v, 0, seq)) continue;
+                if (pend_a > 0) { set_bits(0, shift_done, pend_a); bits_set = true; shift_done += pend_a; __syncthreads(); }
+            }
+            t_shifted = blockIdx.x == 0 ? __builtin_amdgcn_s_memrealtime() : 0;
+            shift_once();
+            if (inline_entries) apply_entries(lm + 16, 0, 1);
+            else if (need_v > 0) apply_entries(lm + kStage + pend_a * 16, 0, need_v);
+        } else {
+            for (int first = shift_done; first < shift_lines; first += kChunk) {
+                const int chunk = shift_lines - first < kChunk ? shift_lines - first : kChunk;
+                if (!fetch(chunk, first, 0, 0, seq)) { torn = true; break; }
+                set_bits(0, first, chunk);
+                bits_set = true;
+                shift_done = first + chunk;
+                __syncthreads();
+            }
+            if (torn) continue;
+            if (apply_only) {
+                last_sub = sub;
+                idle_since = __builtin_amdgcn_s_memrealtime();
+                continue;
+            }
+            t_shifted = blockIdx.x == 0 ? __builtin_amdgcn_s_memrealtime() : 0;
+            shift_once();
+            if (inline_entries) apply_entries(lm + 16, 0, 1);
+            else {
+                for (int first = 0; first < lines; first += kCandRoundLines) {
+                    const int chunk = lines - first < kCandRoundLines ? lines - first : kCandRoundLines;
+                    if (!fetch(0, 0, chunk, first, seq)) { torn = true; break; }
+                    apply_entries(lm + kStage, first, chunk);
+                    __syncthreads();                                                    // the round has been consumed before the next one lands in lm
+                }
+                if (torn) continue;                                                     // value entries are final values: repeating them is harmless; the shift is guarded
+            }
+        }
+        // ---- the state writes that were posted to me
+        if (n_st > 0) {
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                const uint32_t m = sp_mask[t * kCandThreads + tid];
+                if (m) {
+                    mine[t].st4 = (mine[t].st4 & ~m) | (sp_val[t * kCandThreads + tid] & m);
+                    sp_mask[t * kCandThreads + tid] = 0u;
+                    sp_val[t * kCandThreads + tid] = 0u;
+                }
+            }
         }
         // ---- scan
-        int64_t c1, c2;
-        uint32_t p1, p2;
-        fold_tile_best2<T>(mine, ps, pt, p.base + my_i0, c1, p1, c2, p2);
+        const uint64_t t_patched = blockIdx.x == 0 ? __builtin_amdgcn_s_memrealtime() : 0;
+        int64_t c1 = 0, c2 = 0;                         // best and second best of this thread's arcs (its tiles come in increasing arc id)
+        uint32_t p1 = kNone, p2 = kNone;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int st = (int)(int8_t)(mine[t].st4 >> (8 * j));
+                const int64_t dd = (int64_t)mine[t].c.v[j] + (int64_t)ps[t][j] - (int64_t)pt[t][j];
+                const int64_t rc = st > 0 ? dd : (st < 0 ? -dd : 0);
+                const uint32_t e = (uint32_t)(p.base + my_i[t] + j);
+                const bool b1 = rc < c1;
+                const bool b2 = !b1 && rc < c2;
+                c2 = b1 ? c1 : (b2 ? rc : c2);
+                p2 = b1 ? p1 : (b2 ? e : p2);
+                c1 = b1 ? rc : c1;
+                p1 = b1 ? e : p1;
+            }
         publish_candidates(c1, p1, c2, p2, p.slots, seq);
         if (bits_set) {
             for (int i = tid; i < kShiftBits / 32; i += nt) bitmap[i] = 0u;
@@ -1250,7 +1359,11 @@ __global__ __launch_bounds__(kPiRegThreads) void resident_cand_kernel(const Resi
         last = seq;
         served += 1;
         idle_since = __builtin_amdgcn_s_memrealtime();
-        if (blockIdx.x == 0) scan_ticks += idle_since - t_seen;
+        if (blockIdx.x == 0) {
+            scan_ticks += idle_since - t_seen;
+            ph_shift += t_shifted - t_seen; ph_values += t_patched - t_shifted; ph_scan += idle_since - t_patched;
+            n_shift_req += n_shift > 0 ? 1 : 0;
+        }
         __syncthreads();
     }
 }

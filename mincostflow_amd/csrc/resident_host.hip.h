@@ -70,7 +70,10 @@ void launch_resident_r(mcf_engine *e, const ResidentParams<T> &p)
     const bool lpi = e->lds_pi;
     if (e->cand_on) {     // candidates: Best Eligible, register-resident tiles only
         if (e->shift_grid) {
-            if constexpr (sizeof(T) == 8) hipExtLaunchKernelGGL((resident_cand_kernel<T>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p, e->shift_base, e->max_shift_lines);
+            if constexpr (sizeof(T) == 8) {
+                if (e->cand_tiles == 2) hipExtLaunchKernelGGL((resident_cand_kernel<T, 2>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p, e->shift_base, e->max_shift_lines);
+                else hipExtLaunchKernelGGL((resident_cand_kernel<T, 4>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p, e->shift_base, e->max_shift_lines);
+            }
         }
         else if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, true, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
         else if (e->res_threads <= kPiRegThreads && !e->no_pireg)       // the end points' potentials stay in registers between the requests
@@ -186,7 +189,7 @@ int resident_start(mcf_engine *e, uint32_t start_seq)
             if (mcf::now_ns() - t0 > 20e9) return mcf::fail(MCF_ERR_TIMEOUT, "no resident slot on device %d became free within 20 s", e->d.device);
         }
     }
-    for (int i = 0; i < 4; ++i) ((volatile uint32_t *)e->h_exit)[i] = 0;
+    for (int i = 0; i < 16; ++i) ((volatile uint32_t *)e->h_exit)[i] = 0;
     int rc = e->rc_mode ? launch_resident_rc(e, start_seq) : (e->d.int_width == 32 ? launch_resident<int32_t>(e, start_seq) : launch_resident<int64_t>(e, start_seq));
     if (rc) return rc;
     e->resident_running = true;
@@ -333,6 +336,11 @@ void resident_harvest(mcf_engine *e)
     const volatile uint32_t *x = e->h_exit;
     e->st.resident_requests += x[1];
     e->st.resident_scan_ns += 10.0 * (double)(((uint64_t)x[3] << 32) | x[2]);
+    if (e->shift_grid) {
+        auto u64 = [&](int i) { return (double)(((uint64_t)x[i + 1] << 32) | x[i]); };
+        e->st.phase_shift_ns += 10.0 * u64(4); e->st.phase_values_ns += 10.0 * u64(6); e->st.phase_scan_ns += 10.0 * u64(8);
+        if (getenv("MCF_HIP_CAND_DEBUG")) fprintf(stderr, "[grid] shader clock over the launch: %.0f MHz\n", u64(10));
+    }
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->res_start, e->res_stop) == hipSuccess) e->st.resident_kernel_ns += (double)ms * 1e6;
 }

@@ -18,5 +18,6 @@ for rep in range(1 if which == "config5" else 2):
     m = ns.get_metrics(); e = m["engine"]; it = m["iterations"]
     print(f"status {st} pivots {it}  loop {m['loop_us']/1e3:.1f} ms = {m['loop_us']/it:.2f} us/pivot: search {m['pivot_search_us']/it:.2f}, tree {m['tree_update_us']/it:.2f}, "
           f"potential {m['potential_update_us']/it:.2f}; avg subtree {m['potential_nodes']/it:.0f}; device requests {e['resident_requests']} (in-kernel {e['resident_scan_ns']/max(1,e['resident_requests'])/1e3:.2f} us each), "
+          f"phases shift/values/scan {e['phase_shift_ns']/max(1,e['resident_requests'])/1e3:.2f}/{e['phase_values_ns']/max(1,e['resident_requests'])/1e3:.2f}/{e['phase_scan_ns']/max(1,e['resident_requests'])/1e3:.2f} us, shift lists {e['shift_lists']}, "
           f"host-decided {e['host_decided']}, resident launches {e['resident_launches']}, update launches {e['update_launches']}, rc recomputes {e['rc_recomputes']}", flush=True)
     del ns
