@@ -278,11 +278,19 @@ int cand_collect(mcf_engine *e, uint32_t at)
 // (a shift that was not announced, too many entries), the grid is stopped and the values go through update_rc_kernel.
 int cand_post_rc(mcf_engine *e)
 {
+    // a reload of the bound potentials that the grid can carry out itself (cmd 3): the array is read when the request is served, so every
+    // potential change noted up to now is part of it -- the lists are dropped, the state writes travel with the request
+    const bool reload = e->reload_pi && e->d_ext_pi != nullptr && (int64_t)e->sync_arcs.size() <= e->mailbox_max_st;
+    if (reload) {
+        e->pend_node.clear(); e->pend_val.clear();
+        e->sync_nodes.clear(); e->rc_sync.clear(); e->rc_shift_unknown = false;
+        e->blind_count = 0;
+        e->reload_pi = false;
+    }
     const size_t n_b = e->blind_count, n_s = e->rc_sync.size();
     const bool blind_ok = n_b == 0 || (e->pend_shift && e->blind_epoch == e->cand_now);      // shifts add up: a node may sit in both lists
     const int64_t n_st = (int64_t)e->sync_arcs.size();
-    const bool fast = !e->reload_pi && !e->rc_shift_unknown && blind_ok && (int64_t)(n_b + n_s) <= kRcResidentNodes && n_st <= e->mailbox_max_st &&
-                      (int64_t)(n_b + n_s > 1 ? n_b + n_s - 1 : 0) + (n_st > 2 ? n_st - 2 : 0) <= (int64_t)(kMailboxLines - 1) * kMailboxPatchesPerLine;
+    const bool fast = !e->reload_pi && !e->rc_shift_unknown && blind_ok && (int64_t)(n_b + n_s) <= (int64_t)e->rc_list_max && n_st <= e->mailbox_max_st;
     if (fast) {
         e->pend_node.resize(n_b + n_s);
         e->pend_val.resize(n_b + n_s);
@@ -304,7 +312,8 @@ int cand_post_rc(mcf_engine *e)
     if (e->seq == 0) e->seq = 1;
     int rc = resident_start(e, e->prev_seq);
     if (rc) return rc;
-    resident_post(e, e->seq, 0u, fast);
+    resident_post(e, e->seq, reload ? 3u : 0u, fast);
+    if (reload) e->st.rc_reloads_in_grid += 1;
     if (fast && (!e->pend_node.empty() || !e->pend_arc.empty())) e->st.inline_updates += 1;
     e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
     e->posted_at = e->cand_now;

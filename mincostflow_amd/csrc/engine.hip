@@ -120,6 +120,7 @@ struct mcf_engine {
     uint32_t *d_adj = nullptr;     // the shard's arcs at each node: local position, bit 31 = the node is the arc's target
     mcf::hvec<int32_t> h_adj_start;   // host copy of d_adj_start (short lists name their arc lists in the scan's arguments)
     int rc_recompute_above = INT32_MAX;   // RC layout: potential lists longer than this are followed by a full recomputation instead of per-arc shifts
+    int rc_list_max = 0;                  // resident RC grid: {node, shift} entries one request may carry (longer lists stop the grid)
     bool pend_shift = false;       // every pending potential is its node's previous value + pend_sigma (mcf_engine_shift_potential)
     int64_t pend_sigma = 0;
     bool no_pireg = false;         // MCF_ENGINE_SHARE_DEVICE or MCF_HIP_PIREG=0: the resident grid gathers the potentials for every request
@@ -130,6 +131,8 @@ struct mcf_engine {
     mcf::hvec<int64_t> pi;
     bool mirror_valid = false;     // mcf_engine_set_potential stops maintaining the mirror; update_potential rebuilds it on demand
     bool ext_pi_pinned = false;        // the bound array is registered with HIP (the device can copy it by itself): mcf_engine_reload_potentials
+    const int64_t *d_ext_pi = nullptr; // ... and this is where the device sees it: the resident RC grid copies it itself (cmd 3), no stop
+    uint32_t *d_barrier = nullptr;     // counter of that grid's grid-wide barrier
     bool reload_pi = false;            // the whole bound array is to be copied to the device before the next search (and the RC layout recomputed)
     const int64_t *ext_pi = nullptr;   // mcf_engine_bind_potentials: the caller's own array is read instead of the mirror (no second copy to keep up to date)
     int64_t max_abs_cost = 0;
@@ -618,11 +621,16 @@ int search_begin(mcf_engine *e)
     if (resident_now) {
         // ---- resident mode: post the request into the mailbox, the grid is already running
         bool fits = (int)e->pend_arc.size() <= e->mailbox_max_st;     // any number of potentials fits the mailbox
+        bool rc_reload = false;
         if (e->rc_mode) {
             // resident RC grid: a request is one staging chunk of {node, shift} entries; anything else goes through update_rc_kernel with the grid stopped
+            // resident RC grid: a request carries {node, shift} entries, any number the mailbox holds (the grid works them off in chunks); a
+            // reload of the bound potentials is a request too (cmd 3) when the device can read the array itself.  Anything else -- a change
+            // that came without its shift, a reload of an array the device cannot see -- goes through update_rc_kernel with the grid stopped
+            rc_reload = e->reload_pi && e->d_ext_pi != nullptr;
+            if (rc_reload) { e->pend_node.clear(); e->pend_val.clear(); e->reload_pi = false; }          // whatever was announced since is part of the array
             const int64_t n_pi = (int64_t)e->pend_node.size(), n_st = (int64_t)e->pend_arc.size();
-            fits = !e->reload_pi && (n_pi == 0 || e->pend_shift) && n_pi <= kRcResidentNodes &&
-                   (n_pi > 1 ? n_pi - 1 : 0) + (n_st > 2 ? n_st - 2 : 0) <= (int64_t)(kMailboxLines - 1) * kMailboxPatchesPerLine;
+            fits = !e->reload_pi && (n_pi == 0 || e->pend_shift) && n_pi <= (int64_t)e->rc_list_max && n_st <= e->mailbox_max_st;
             if (fits && n_pi > 0) std::fill(e->pend_val.begin(), e->pend_val.end(), e->pend_sigma);      // the entries carry the shift, not the value
         }
         if (!fits) {
@@ -636,7 +644,8 @@ int search_begin(mcf_engine *e)
         if (e->seq == 0) e->seq = 1;
         int rc = resident_start(e, e->prev_seq);
         if (rc) return rc;
-        resident_post(e, e->seq, 0u, fits);
+        resident_post(e, e->seq, rc_reload ? 3u : 0u, fits);
+        if (rc_reload) e->st.rc_reloads_in_grid += 1;
         if (fits) {
             if (had) e->st.inline_updates += 1;
             e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
@@ -895,6 +904,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
             // workgroups of 256 .. 1024 threads lands within 14.3-15.6 us warm / 16.6-17.7 cold for 81 MB; 512 x 256 with two tiles per trip is
             // the best of them, more workgroups only add launch ramp and tail
             e->rc_recompute_above = std::max(1024, desc->node_count / 16);
+            e->rc_list_max = std::min(2 * desc->node_count, std::max(kRcResidentNodes, e->rc_recompute_above));
             if (const char *u = getenv("MCF_HIP_RC_RECOMPUTE")) { const long long v = atoll(u); e->rc_recompute_above = v <= 0 || v > INT32_MAX ? INT32_MAX : (int)v; }    // 0: never
             e->unroll = count > (1 << 20) ? 2 : 1;
             if (const char *u = getenv("MCF_HIP_UNROLL")) { const int v = atoi(u); if (v == 1 || v == 2 || v == 4) e->unroll = v; }
@@ -1034,7 +1044,7 @@ bool host_pin(const void *p, size_t bytes)
     std::lock_guard<std::mutex> lock(g_pin_mutex);
     auto it = g_pins.find(p);
     if (it != g_pins.end()) { it->second += 1; return true; }
-    const hipError_t r = hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterPortable);
+    const hipError_t r = hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterPortable | hipHostRegisterMapped);
     (void)hipGetLastError();                      // a refusal is not an error of the engine: it then takes node lists only
     if (r != hipSuccess) return false;
     g_pins[p] = 1;
@@ -1073,7 +1083,7 @@ void mcf_engine_destroy(mcf_engine *e)
     if (e->res_stop) (void)hipEventDestroy(e->res_stop);
     if (e->comm && rccl() && rccl()->comm_destroy) rccl()->comm_destroy(e->comm);
     if (e->d_orig) (void)hipFree(e->d_orig);
-    (void)hipFree(e->d_rc); (void)hipFree(e->d_adj_start); (void)hipFree(e->d_adj);
+    (void)hipFree(e->d_rc); (void)hipFree(e->d_adj_start); (void)hipFree(e->d_adj); (void)hipFree(e->d_barrier);
     (void)hipFree(e->d_src); (void)hipFree(e->d_tgt); (void)hipFree(e->d_cost); (void)hipFree(e->d_state); (void)hipFree(e->d_pi);
     (void)hipFree(e->d_cand_local); (void)hipFree(e->d_cand_all); (void)hipFree(e->d_flush); (void)hipFree(e->d_dev_slots);
     if (e->h_cand_all) (void)hipHostFree(e->h_cand_all);
@@ -1344,9 +1354,16 @@ int mcf_engine_bind_potentials(mcf_engine *e, const int64_t *pi)
     if (!pi) e->mirror_valid = false;
     // RC layout, 64-bit potentials: the array is made known to HIP so that a reload (mcf_engine_reload_potentials) is one asynchronous copy.
     // Several engines of one solver bind the same array: the first registers it, the others find it registered.
+    e->d_ext_pi = nullptr;
     if (pi && e->rc_mode && e->d.int_width == 64) {
         (void)hipSetDevice(e->d.device);
         e->ext_pi_pinned = host_pin(pi, sizeof(int64_t) * (size_t)e->d.node_count);
+        if (e->ext_pi_pinned && e->resident_ok && !(getenv("MCF_HIP_RC_INGRID_RELOAD") && getenv("MCF_HIP_RC_INGRID_RELOAD")[0] == '0')) {
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, const_cast<int64_t *>(pi), 0) == hipSuccess) e->d_ext_pi = (const int64_t *)dp;
+            (void)hipGetLastError();
+            if (!e->d_barrier && hipMalloc((void **)&e->d_barrier, 64) != hipSuccess) { e->d_barrier = nullptr; e->d_ext_pi = nullptr; (void)hipGetLastError(); }
+        }
     }
     return MCF_OK;
 }

@@ -1379,7 +1379,7 @@ __global__ __launch_bounds__(kCandThreads) void resident_cand_kernel(const Resid
 // by its only reader.  A request fits one staging chunk (kRcResidentNodes nodes); the host sends longer lists through update_rc_kernel with the
 // grid stopped.
 constexpr int kRcWindow = 8192;                    // arcs per workgroup in LDS: 64 KB of reduced costs + 8 KB of states
-constexpr int kRcResidentNodes = 1 + 255 * kMailboxPatchesPerLine - 8;   // one chunk of entry lines, a few entries left for state patches
+constexpr int kRcResidentNodes = 1 + 255 * kMailboxPatchesPerLine - 8;   // moved nodes that fit ONE staging chunk of entry lines (longer lists take several)
 
 // running best and second best (c, arc) of a thread's arcs in the RC layout (candidate variant of resident_rc_kernel, Best Eligible only)
 __device__ __forceinline__ void fold_rc_best2(uint32_t st4, const int64_t d[4], int e0, int64_t &c1, uint32_t &p1, int64_t &c2, uint32_t &p2)
@@ -1408,16 +1408,29 @@ struct ResidentRcParams {
     Slot *slots;
     const uint32_t *mailbox;
     uint32_t *exit_word;
+    // in-grid reload (cmd 3): the arcs' end points and costs, the caller's bound potentials as the device sees them (mapped host memory; nullptr:
+    // the host never posts a reload), and a counter in device memory for the grid-wide barrier (zeroed by the host before every launch)
+    const int32_t *src, *tgt;
+    const void *cost;
+    const int64_t *host_pi;
+    uint32_t *barrier;
     int32_t base, count_padded, m_s, window;       // window: arcs per workgroup (LD), multiple of 4 * blockDim
     uint32_t start_seq, idle_ticks;
-    int32_t narrow, max_pi, max_st, poll_replicas, poll_sleep;
+    int32_t narrow, max_pi, max_st, poll_replicas, poll_sleep, n_nodes;
 };
 
+// A request of this grid: the State[] writes and the moved nodes WITH THEIR SHIFT ({node, delta}), any number of them: the entry lines are
+// staged and worked off in chunks of one staging area (255 lines).  Shifts are atomics -- applying a chunk twice would be wrong -- so the
+// grid remembers how far it got with the request it is working on (a torn line makes it poll again and resume there).
+//   cmd 3 (reload): "the bound potentials in host memory are current, every potential may have changed": the workgroups copy the array
+//   (each its share, over PCIe), meet at a grid-wide barrier, and every workgroup computes the reduced costs of ITS arcs again -- what
+//   mcf_engine_reload_potentials used to stop the grid for (memcpy + rc_init_kernel + a new launch).
 template <int RULE, bool OPT, bool LD, bool CAND = false>
 __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const ResidentRcParams p)
 {
     static_assert(!CAND || RULE == MCF_RULE_BEST_ELIGIBLE, "candidate lists serve Best Eligible");
     constexpr int kLines = kMailboxLines;                      // line 0 + one chunk of 255 entry lines
+    constexpr int kChunk = kLines - 1;
     constexpr int kNodesMax = 1280;
     __shared__ __attribute__((aligned(16))) uint32_t lm[kLines * 16];
     __shared__ __attribute__((aligned(16))) int64_t ld[LD ? kRcWindow : 2];      // reduced costs of my window
@@ -1427,10 +1440,11 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
     __shared__ uint32_t s_timeout;
     const int tid = threadIdx.x, nt = (int)blockDim.x;
     const int w_lo = LD ? (int)blockIdx.x * p.window : 0;                       // first position of my window
-    if (LD) {
+    typedef long v2l __attribute__((ext_vector_type(2)));
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    auto load_window = [&]() {
         for (int i = tid * 4; i < p.window; i += nt * 4) {
             const int g = w_lo + i;
-            typedef long v2l __attribute__((ext_vector_type(2)));
             if (g < p.count_padded) {
                 *reinterpret_cast<v2l *>(ld + i) = *reinterpret_cast<const v2l *>(p.rc + g);
                 *reinterpret_cast<v2l *>(ld + i + 2) = *reinterpret_cast<const v2l *>(p.rc + g + 2);
@@ -1441,14 +1455,61 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
             }
         }
         __syncthreads();
-    }
-    uint32_t last = p.start_seq, served = 0;
+    };
+    if (LD) load_window();
+    uint32_t last = p.start_seq, served = 0, prog_seq = p.start_seq, barriers = 0;
+    int prog_lines = 0;                                        // entry lines of request prog_seq already worked off
+    bool prog_header = false;                                  // ... and its header entries
     uint64_t scan_ticks = 0;
     uint64_t idle_since = __builtin_amdgcn_s_memrealtime();
     const uint32_t *const my_unit = p.mailbox + (size_t)(blockIdx.x % p.poll_replicas) * kReplicaStride;
+    // one moved node's arcs: shift those of MY window (LDS copy and memory), each arc exactly once, by its only reader
+    auto shift_lists = [&](int n_here) {
+        if (tid == 0) s_pre[0] = 0;
+        __syncthreads();
+        // inclusive scan of the list lengths (Hillis-Steele over at most kNodesMax entries; every thread owns up to two)
+        for (int off = 1; off < n_here; off <<= 1) {
+            int v0 = 0, v1 = 0;
+            const int i0 = tid + 1, i1 = tid + 1 + nt;
+            if (i0 <= n_here && i0 - off >= 1) v0 = s_pre[i0 - off];
+            if (i1 <= n_here && i1 - off >= 1) v1 = s_pre[i1 - off];
+            __syncthreads();
+            if (i0 <= n_here) s_pre[i0] += v0;
+            if (i1 <= n_here) s_pre[i1] += v1;
+            __syncthreads();
+        }
+        const int total = s_pre[n_here];
+        for (int f = tid; f < total; f += nt) {
+            int k = 0;
+            for (int step = 1024; step > 0; step >>= 1)           // largest k < n_here with s_pre[k] <= f
+                if (k + step < n_here && s_pre[k + step] <= f) k += step;
+            const uint32_t x = p.adj[s_lo[k] + (f - s_pre[k])];
+            const int pos = (int)(x & 0x7FFFFFFFu);
+            const bool mine = LD ? (pos >= w_lo && pos < w_lo + p.window) : ((int)(((uint32_t)pos / (uint32_t)(nt * kArcsPerThread)) % gridDim.x) == (int)blockIdx.x);
+            if (mine) {
+                const long long add = (x >> 31) ? -s_delta[k] : s_delta[k];
+                atomicAdd(reinterpret_cast<unsigned long long *>(p.rc + pos), (unsigned long long)add);
+                if (LD) atomicAdd(reinterpret_cast<unsigned long long *>(ld + (pos - w_lo)), (unsigned long long)add);
+            }
+        }
+        if (blockIdx.x == 0) {
+            for (int i = tid; i < n_here; i += nt) {
+                // atomics: the candidate cache's requests carry several pivots' lists, a node may come more than once
+                if (p.narrow) atomicAdd(reinterpret_cast<int32_t *>(p.pi) + s_node[i], (int32_t)s_delta[i]);
+                else atomicAdd(reinterpret_cast<unsigned long long *>(p.pi) + s_node[i], (unsigned long long)s_delta[i]);
+            }
+        }
+        __syncthreads();                                       // s_node .. s_pre are reused by the next chunk
+    };
+    auto state_write = [&](int arc, uint32_t val) {            // final values (memory: every workgroup, idempotent; LDS copy: the window's owner)
+        const int a = arc - p.base;
+        if ((unsigned)a < (unsigned)p.count_padded) {
+            p.state[a] = (int8_t)val;
+            if (LD && a >= w_lo && a < w_lo + p.window) ls[a - w_lo] = (int8_t)val;
+        }
+    };
     for (;;) {
         if (tid < 64) {                                        // wave 0 polls lines 0 and 1 (see resident_kernel)
-            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
             v4u x = v4u{0u, 0u, 0u, 0u};
             uint32_t flag;
             for (;;) {
@@ -1468,7 +1529,7 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
         n_pi = n_pi < 0 ? 0 : (n_pi > p.max_pi ? p.max_pi : n_pi);
         n_st = n_st < 0 ? 0 : (n_st > p.max_st ? p.max_st : n_st);
         const int extra_pi = n_pi > 1 ? n_pi - 1 : 0, extra_st = n_st > 2 ? n_st - 2 : 0, entries = extra_pi + extra_st;
-        const int lines = 1 + (entries + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;      // <= kLines by the host's contract
+        const int lines = (entries + kMailboxPatchesPerLine - 1) / kMailboxPatchesPerLine;
         const bool timed_out = s_timeout == 2u;
         const bool line1_staged = lm[31] == seq;
         const int next_arc = (int)lm[2], rstar = (int)lm[3];
@@ -1476,7 +1537,7 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
         const int st_arc0 = (int)lm[6], st_arc1 = (int)lm[8];
         const uint32_t st_val0 = lm[7], st_val1 = lm[9];
         const uint32_t p0_node = lm[10], p0_lo = lm[11], p0_hi = lm[12];
-        if (lines > 1) __syncthreads();
+        __syncthreads();                                       // everybody has read lines 0 and 1 before entry lines land in lm
         if (timed_out) {
             if (tid == 0 && blockIdx.x == 0) resident_exit(p.exit_word, 2u, served, scan_ticks);
             return;
@@ -1486,94 +1547,129 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
             if (tid == 0 && blockIdx.x == 0) resident_exit(p.exit_word, 1u, served, scan_ticks);
             return;
         }
-        // ---- the entry lines (one chunk), each verified by its tag
+        if (prog_seq != seq) { prog_seq = seq; prog_lines = 0; prog_header = false; }
+        // ---- reload: every potential anew from the caller's array, every reduced cost of my arcs anew from them
+        if (cmd == 3u && !prog_header && p.host_pi) {
+            const int per = (p.n_nodes + (int)gridDim.x - 1) / (int)gridDim.x;
+            const int lo = (int)blockIdx.x * per, hi = lo + per < p.n_nodes ? lo + per : p.n_nodes;
+            for (int i = lo + tid; i < hi; i += nt) {
+                const int64_t v = p.host_pi[i];
+                // agent scope: written through to memory, where the workgroups of the other XCDs (each with an L2 of its own) will find it
+                if (p.narrow) __hip_atomic_store(reinterpret_cast<int32_t *>(p.pi) + i, (int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else __hip_atomic_store(reinterpret_cast<int64_t *>(p.pi) + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            // grid-wide barrier: all workgroups are resident (one per CU), so everybody arrives
+            barriers += 1;
+            if (tid == 0) {
+                __hip_atomic_fetch_add(p.barrier, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t want = barriers * gridDim.x;
+                const uint64_t t_bar = __builtin_amdgcn_s_memrealtime();
+                uint32_t gave_up = 0u;
+                while (__hip_atomic_load(p.barrier, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(2);
+                    // every spin is bounded: a workgroup that never got a CU (somebody else's grid holds them) must not hang the others.
+                    // The grid leaves with code 3; the host starts it again and the reload, which overwrites everything, runs from the start
+                    if (__builtin_amdgcn_s_memrealtime() - t_bar > 8ull * p.idle_ticks) { gave_up = 1u; break; }
+                }
+                s_timeout = gave_up ? 3u : 0u;
+            }
+            __syncthreads();
+            if (s_timeout == 3u) {
+                if (tid == 0) resident_exit(p.exit_word, 3u, served, scan_ticks);
+                return;
+            }
+            // this CU's L1 and this XCD's L2 may hold potentials from before: forget them (once per workgroup; the acquire above did it for
+            // wave 0's view, the explicit invalidate makes it hold for the loads of every wave that follow the barrier)
+            if (tid < 64) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int step = LD ? nt * kArcsPerThread : (int)gridDim.x * nt * kArcsPerThread;
+            const int begin = LD ? w_lo + tid * kArcsPerThread : (int)blockIdx.x * nt * kArcsPerThread + tid * kArcsPerThread;
+            const int end = LD ? (w_lo + p.window < p.count_padded ? w_lo + p.window : p.count_padded) : p.count_padded;
+            for (int i0 = begin; i0 < end; i0 += step) {
+                const int4 s4 = *reinterpret_cast<const int4 *>(p.src + i0), t4 = *reinterpret_cast<const int4 *>(p.tgt + i0);
+                const int sv[4] = {s4.x, s4.y, s4.z, s4.w}, tv[4] = {t4.x, t4.y, t4.z, t4.w};
+                int64_t d[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (p.narrow) d[j] = (int64_t)reinterpret_cast<const int32_t *>(p.cost)[i0 + j] + (int64_t)reinterpret_cast<const int32_t *>(p.pi)[sv[j]] - (int64_t)reinterpret_cast<const int32_t *>(p.pi)[tv[j]];
+                    else d[j] = reinterpret_cast<const int64_t *>(p.cost)[i0 + j] + reinterpret_cast<const int64_t *>(p.pi)[sv[j]] - reinterpret_cast<const int64_t *>(p.pi)[tv[j]];
+                }
+                *reinterpret_cast<v2l *>(p.rc + i0) = v2l{d[0], d[1]};
+                *reinterpret_cast<v2l *>(p.rc + i0 + 2) = v2l{d[2], d[3]};
+                if (LD) { ld[i0 - w_lo] = d[0]; ld[i0 - w_lo + 1] = d[1]; ld[i0 - w_lo + 2] = d[2]; ld[i0 - w_lo + 3] = d[3]; }
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+        }
+        // ---- header entries: moved node 0 {node, delta}, state writes 0 and 1
+        if (!prog_header) {
+            if (n_pi > 0 && cmd != 3u) {
+                if (tid == 0) {
+                    s_node[0] = (int)p0_node;
+                    s_delta[0] = (int64_t)(((uint64_t)p0_hi << 32) | p0_lo);
+                    const int a0 = p.adj_start[p0_node], a1 = p.adj_start[p0_node + 1];
+                    s_lo[0] = a0;
+                    s_pre[1] = a1 - a0;
+                }
+                shift_lists(1);
+            }
+            if (tid == 0 && n_st > 0) state_write(st_arc0, st_val0);
+            if (tid == 1 && n_st > 1) state_write(st_arc1, st_val1);
+            prog_header = true;
+        }
+        // ---- the entry lines in chunks, each line verified by its tag: moved nodes 1.., then state writes 2..
         bool torn = false;
-        if (lines > 1) {
-            const int chunk = lines - 1;
-            const bool staged = chunk == 1 && line1_staged;
-            for (int base = 0; base < chunk * 4 && !staged; base += nt) {
-                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                const int c = base + tid;
-                if (c < chunk * 4) {
-                    const int line = 1 + (c >> 2);
-                    const uint32_t *src = line == 1 ? my_unit + 16 + (c & 3) * 4 : p.mailbox + (kMailboxTail + (size_t)(line - 2) * 16 + (c & 3) * 4);
-                    v4u x;
-                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x) : "v"(src) : "memory");
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)::"memory");
-                    *reinterpret_cast<v4u *>(lm + 16 + c * 4) = x;
+        for (int first = prog_lines; first < lines; first += kChunk) {
+            const int chunk = lines - first < kChunk ? lines - first : kChunk;
+            const bool staged = first == 0 && chunk == 1 && line1_staged;
+            if (!staged) {                                     // (a single line that came with the poll is in place already)
+                for (int base = 0; base < chunk * 4; base += nt) {
+                    const int c = base + tid;
+                    if (c < chunk * 4) {
+                        const int line = first + (c >> 2);          // entry line 0 sits in the poll unit, the others in the tail
+                        const uint32_t *src = line == 0 ? my_unit + 16 + (c & 3) * 4 : p.mailbox + (kMailboxTail + (size_t)(line - 1) * 16 + (c & 3) * 4);
+                        v4u x;
+                        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x) : "v"(src) : "memory");
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)::"memory");
+                        *reinterpret_cast<v4u *>(lm + 16 + c * 4) = x;
+                    }
                 }
             }
             __syncthreads();
             int bad = 0;
             for (int l = tid; l < chunk; l += nt) bad |= (lm[(1 + l) * 16 + 15] != seq);
-            torn = __syncthreads_or(bad) != 0;
-        }
-        if (torn) continue;                                    // a line was still in flight: poll again (nothing has been applied yet)
-        // ---- moved nodes: {node, delta}; entry 0 rides in the header
-        for (int i = tid; i < n_pi; i += nt) {
-            uint32_t node, lo, hi;
-            if (i == 0) { node = p0_node; lo = p0_lo; hi = p0_hi; }
-            else { const uint32_t *q = lm + (1 + (i - 1) / kMailboxPatchesPerLine) * 16 + 3 * ((i - 1) % kMailboxPatchesPerLine); node = q[0]; lo = q[1]; hi = q[2]; }
-            const int a0 = p.adj_start[node], a1 = p.adj_start[node + 1];
-            s_node[i] = (int)node;
-            s_delta[i] = (int64_t)(((uint64_t)hi << 32) | lo);
-            s_lo[i] = a0;
-            s_pre[i + 1] = a1 - a0;
-        }
-        if (tid == 0) s_pre[0] = 0;
-        __syncthreads();
-        if (n_pi > 0) {
-            // inclusive scan of the list lengths (Hillis-Steele over at most kNodesMax entries; every thread owns up to two)
-            for (int off = 1; off < n_pi; off <<= 1) {
-                int v0 = 0, v1 = 0;
-                const int i0 = tid + 1, i1 = tid + 1 + nt;
-                if (i0 <= n_pi && i0 - off >= 1) v0 = s_pre[i0 - off];
-                if (i1 <= n_pi && i1 - off >= 1) v1 = s_pre[i1 - off];
-                __syncthreads();
-                if (i0 <= n_pi) s_pre[i0] += v0;
-                if (i1 <= n_pi) s_pre[i1] += v1;
-                __syncthreads();
+            if (__syncthreads_or(bad)) { torn = true; break; }
+            const int i_lo = first * kMailboxPatchesPerLine;
+            const int i_hi = entries < i_lo + chunk * kMailboxPatchesPerLine ? entries : i_lo + chunk * kMailboxPatchesPerLine;
+            const int pi_hi = i_hi < extra_pi ? i_hi : extra_pi;                     // moved nodes of this chunk: [i_lo, pi_hi)
+            const int n_here = pi_hi > i_lo ? pi_hi - i_lo : 0;
+            for (int i = tid; i < n_here; i += nt) {
+                const uint32_t *q = lm + (1 + i / kMailboxPatchesPerLine) * 16 + 3 * (i % kMailboxPatchesPerLine);
+                const uint32_t node = q[0];
+                const int a0 = p.adj_start[node], a1 = p.adj_start[node + 1];
+                s_node[i] = (int)node;
+                s_delta[i] = (int64_t)(((uint64_t)q[2] << 32) | q[1]);
+                s_lo[i] = a0;
+                s_pre[i + 1] = a1 - a0;
             }
-            const int total = s_pre[n_pi];
-            for (int f = tid; f < total; f += nt) {
-                int k = 0;
-                for (int step = 1024; step > 0; step >>= 1)           // largest k < n_pi with s_pre[k] <= f
-                    if (k + step < n_pi && s_pre[k + step] <= f) k += step;
-                const uint32_t x = p.adj[s_lo[k] + (f - s_pre[k])];
-                const int pos = (int)(x & 0x7FFFFFFFu);
-                const bool mine = LD ? (pos >= w_lo && pos < w_lo + p.window) : ((int)(((uint32_t)pos / (uint32_t)(nt * kArcsPerThread)) % gridDim.x) == (int)blockIdx.x);
-                if (mine) {
-                    const long long add = (x >> 31) ? -s_delta[k] : s_delta[k];
-                    atomicAdd(reinterpret_cast<unsigned long long *>(p.rc + pos), (unsigned long long)add);
-                    if (LD) atomicAdd(reinterpret_cast<unsigned long long *>(ld + (pos - w_lo)), (unsigned long long)add);
-                }
+            if (n_here > 0 && cmd != 3u) shift_lists(n_here);
+            for (int i = (i_lo > extra_pi ? i_lo : extra_pi) + tid; i < i_hi; i += nt) {
+                const int rel = i - i_lo;
+                const uint32_t *q = lm + (1 + rel / kMailboxPatchesPerLine) * 16 + 3 * (rel % kMailboxPatchesPerLine);
+                state_write((int)q[0], q[1]);
             }
-            if (blockIdx.x == 0) {
-                for (int i = tid; i < n_pi; i += nt) {
-                    // atomics: the candidate cache's requests carry several pivots' lists, a node may come more than once
-                    if (p.narrow) atomicAdd(reinterpret_cast<int32_t *>(p.pi) + s_node[i], (int32_t)s_delta[i]);
-                    else atomicAdd(reinterpret_cast<unsigned long long *>(p.pi) + s_node[i], (unsigned long long)s_delta[i]);
-                }
-            }
+            prog_lines = first + chunk;
+            __syncthreads();                                   // the chunk has been consumed before the next one lands in lm
         }
-        // ---- State[] writes: final values (memory: every workgroup, idempotent; LDS copy: the window's owner)
-        for (int i = tid; i < n_st; i += nt) {
-            int arc; uint32_t val;
-            if (i == 0) { arc = st_arc0; val = st_val0; }
-            else if (i == 1) { arc = st_arc1; val = st_val1; }
-            else { const int j = extra_pi + (i - 2); const uint32_t *q = lm + (1 + j / kMailboxPatchesPerLine) * 16 + 3 * (j % kMailboxPatchesPerLine); arc = (int)q[0]; val = q[1]; }
-            const int a = arc - p.base;
-            if ((unsigned)a < (unsigned)p.count_padded) {
-                p.state[a] = (int8_t)val;
-                if (LD && a >= w_lo && a < w_lo + p.window) ls[a - w_lo] = (int8_t)val;
-            }
-        }
+        if (torn) continue;                                    // a line was still in flight: poll again and resume behind what has been applied
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         // The shifts above are atomics performed in this XCD's L2; a line of d that this CU's L1 still holds from an earlier request would be
         // stale.  Only the L1 has to forget it (buffer_inv sc0: the L1 alone -- an agent-scope invalidate also walks the L2 and cost 30 us
         // per request when every wave issued one).  The LDS variant never reads d from memory again.
-        if (!LD && n_pi) asm volatile("buffer_inv sc0\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        if (!LD && (n_pi || cmd == 3u)) asm volatile("buffer_inv sc0\n\ts_waitcnt vmcnt(0)" ::: "memory");
         // ---- scan
         Key best{0, kNone, kNone}, range{0, kNone, kNone};
         int64_t c1 = 0, c2 = 0;              // CAND: best and second best of this thread's arcs
@@ -1586,7 +1682,6 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
                 else fold_rc<RULE, OPT>(st4, d, p.base + w_lo + i, p.m_s, next_arc, block_size, rstar, best, range);
             }
         } else {
-            typedef long v2l __attribute__((ext_vector_type(2)));
             const int step = gridDim.x * nt * kArcsPerThread;
             for (int i0 = blockIdx.x * nt * kArcsPerThread + tid * kArcsPerThread; i0 < p.count_padded; i0 += step) {
                 const uint32_t st4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p.state + i0));

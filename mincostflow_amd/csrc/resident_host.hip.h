@@ -118,7 +118,10 @@ int launch_resident_rc(mcf_engine *e, uint32_t start_seq)
     p.mailbox = e->mailbox; p.exit_word = e->d_exit;
     p.base = e->begin; p.count_padded = e->count_padded; p.m_s = e->d.search_arc_num; p.window = e->rc_window;
     p.start_seq = start_seq; p.idle_ticks = kResidentIdleTicks; p.narrow = e->d.int_width == 32 ? 1 : 0;
-    p.max_pi = kRcResidentNodes; p.max_st = e->mailbox_max_st; p.poll_replicas = e->poll_replicas; p.poll_sleep = e->poll_sleep;
+    p.max_pi = e->patch_capacity; p.max_st = e->mailbox_max_st; p.poll_replicas = e->poll_replicas; p.poll_sleep = e->poll_sleep;
+    p.src = e->d_src; p.tgt = e->d_tgt; p.cost = e->d_cost; p.n_nodes = e->d.node_count;
+    p.host_pi = e->d_ext_pi; p.barrier = e->d_barrier;
+    if (e->d_barrier) HIP_TRY(hipMemsetAsync(e->d_barrier, 0, 64, e->stream));
     switch (e->d.rule) {
     case MCF_RULE_BEST_ELIGIBLE: launch_resident_rc_r<MCF_RULE_BEST_ELIGIBLE, false>(e, p); break;
     case MCF_RULE_FIRST_ELIGIBLE: launch_resident_rc_r<MCF_RULE_FIRST_ELIGIBLE, false>(e, p); break;
