@@ -236,6 +236,12 @@ int cand_collect(mcf_engine *e, uint32_t at)
         while (!cand_records_ready(e, g)) {
             _mm_pause();
             if (e->resident_running && (spins & 0xFFF) == 0xFFF && ((const volatile uint32_t *)e->h_exit)[0] != 0) {
+                if (((const volatile uint32_t *)e->h_exit)[0] == 4u) {
+                    (void)hipStreamSynchronize(e->stream);
+                    e->resident_running = false;
+                    resident_slot_release(e);
+                    return mcf::fail(MCF_ERR_TIMEOUT, "the resident grid could not meet at its grid-wide barrier while a list was being applied (are its workgroups all resident?): the device arrays are undefined");
+                }
                 int rc = resident_restart(e);
                 if (rc) return rc;
             }

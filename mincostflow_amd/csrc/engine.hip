@@ -904,7 +904,7 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
             // workgroups of 256 .. 1024 threads lands within 14.3-15.6 us warm / 16.6-17.7 cold for 81 MB; 512 x 256 with two tiles per trip is
             // the best of them, more workgroups only add launch ramp and tail
             e->rc_recompute_above = std::max(1024, desc->node_count / 16);
-            e->rc_list_max = std::min(2 * desc->node_count, std::max(kRcResidentNodes, e->rc_recompute_above));
+            e->rc_list_max = kRcResidentNodes;
             if (const char *u = getenv("MCF_HIP_RC_RECOMPUTE")) { const long long v = atoll(u); e->rc_recompute_above = v <= 0 || v > INT32_MAX ? INT32_MAX : (int)v; }    // 0: never
             e->unroll = count > (1 << 20) ? 2 : 1;
             if (const char *u = getenv("MCF_HIP_UNROLL")) { const int v = atoi(u); if (v == 1 || v == 2 || v == 4) e->unroll = v; }
@@ -995,6 +995,9 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
                     e->rc_lds = e->rc_window <= kRcWindow && !(getenv("MCF_HIP_RC_LDS") && getenv("MCF_HIP_RC_LDS")[0] == '0');
                     if (!e->rc_lds) e->rc_window = 0;
                     e->resident_reg = false;
+                    // the grid-wide barrier of that grid (long lists are dealt out, reloads are carried out in the grid): one counter in device memory
+                    if (!(getenv("MCF_HIP_RC_BARRIER") && getenv("MCF_HIP_RC_BARRIER")[0] == '0') && hipMalloc((void **)&e->d_barrier, 64) != hipSuccess) { e->d_barrier = nullptr; (void)hipGetLastError(); }
+                    e->rc_list_max = e->d_barrier ? std::min(2 * desc->node_count, std::max(kRcResidentNodes, e->rc_recompute_above)) : kRcResidentNodes;
                 }
                 e->cand_on = !(desc->flags & MCF_ENGINE_NO_CANDIDATES) && !(getenv("MCF_HIP_CANDIDATES") && getenv("MCF_HIP_CANDIDATES")[0] == '0') &&
                              (e->resident_reg || e->rc_mode) && desc->rule == MCF_RULE_BEST_ELIGIBLE && desc->node_count < (1 << 29) &&
@@ -1360,9 +1363,8 @@ int mcf_engine_bind_potentials(mcf_engine *e, const int64_t *pi)
         e->ext_pi_pinned = host_pin(pi, sizeof(int64_t) * (size_t)e->d.node_count);
         if (e->ext_pi_pinned && e->resident_ok && !(getenv("MCF_HIP_RC_INGRID_RELOAD") && getenv("MCF_HIP_RC_INGRID_RELOAD")[0] == '0')) {
             void *dp = nullptr;
-            if (hipHostGetDevicePointer(&dp, const_cast<int64_t *>(pi), 0) == hipSuccess) e->d_ext_pi = (const int64_t *)dp;
+            if (e->d_barrier && hipHostGetDevicePointer(&dp, const_cast<int64_t *>(pi), 0) == hipSuccess) e->d_ext_pi = (const int64_t *)dp;
             (void)hipGetLastError();
-            if (!e->d_barrier && hipMalloc((void **)&e->d_barrier, 64) != hipSuccess) { e->d_barrier = nullptr; e->d_ext_pi = nullptr; (void)hipGetLastError(); }
         }
     }
     return MCF_OK;

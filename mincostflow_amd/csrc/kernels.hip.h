@@ -1508,6 +1508,30 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
             if (LD && a >= w_lo && a < w_lo + p.window) ls[a - w_lo] = (int8_t)val;
         }
     };
+    // grid-wide barrier (all workgroups are resident: one per CU).  Returns false when it gave up: a workgroup that never got a CU
+    // (somebody else's grid holds them) must not hang the others -- every spin of this kernel is bounded.
+    auto grid_barrier = [&]() -> bool {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        barriers += 1;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(p.barrier, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t want = barriers * gridDim.x;
+            const uint64_t t_bar = __builtin_amdgcn_s_memrealtime();
+            uint32_t gave_up = 0u;
+            while (__hip_atomic_load(p.barrier, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t_bar > 8ull * p.idle_ticks) { gave_up = 1u; break; }
+            }
+            s_timeout = gave_up ? 3u : 0u;
+        }
+        __syncthreads();
+        if (s_timeout == 3u) return false;
+        // what other XCDs wrote through to memory may still sit in this CU's L1 / this XCD's L2 in its old form: forget it (once per workgroup)
+        if (tid < 64) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        return true;
+    };
     for (;;) {
         if (tid < 64) {                                        // wave 0 polls lines 0 and 1 (see resident_kernel)
             v4u x = v4u{0u, 0u, 0u, 0u};
@@ -1558,32 +1582,11 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
                 if (p.narrow) __hip_atomic_store(reinterpret_cast<int32_t *>(p.pi) + i, (int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else __hip_atomic_store(reinterpret_cast<int64_t *>(p.pi) + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            // grid-wide barrier: all workgroups are resident (one per CU), so everybody arrives
-            barriers += 1;
-            if (tid == 0) {
-                __hip_atomic_fetch_add(p.barrier, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t want = barriers * gridDim.x;
-                const uint64_t t_bar = __builtin_amdgcn_s_memrealtime();
-                uint32_t gave_up = 0u;
-                while (__hip_atomic_load(p.barrier, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                    __builtin_amdgcn_s_sleep(2);
-                    // every spin is bounded: a workgroup that never got a CU (somebody else's grid holds them) must not hang the others.
-                    // The grid leaves with code 3; the host starts it again and the reload, which overwrites everything, runs from the start
-                    if (__builtin_amdgcn_s_memrealtime() - t_bar > 8ull * p.idle_ticks) { gave_up = 1u; break; }
-                }
-                s_timeout = gave_up ? 3u : 0u;
-            }
-            __syncthreads();
-            if (s_timeout == 3u) {
+            if (!grid_barrier()) {
+                // the grid leaves with code 3; the host starts it again and the reload, which overwrites everything, runs from the start
                 if (tid == 0) resident_exit(p.exit_word, 3u, served, scan_ticks);
                 return;
             }
-            // this CU's L1 and this XCD's L2 may hold potentials from before: forget them (once per workgroup; the acquire above did it for
-            // wave 0's view, the explicit invalidate makes it hold for the loads of every wave that follow the barrier)
-            if (tid < 64) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
             const int step = LD ? nt * kArcsPerThread : (int)gridDim.x * nt * kArcsPerThread;
             const int begin = LD ? w_lo + tid * kArcsPerThread : (int)blockIdx.x * nt * kArcsPerThread + tid * kArcsPerThread;
             const int end = LD ? (w_lo + p.window < p.count_padded ? w_lo + p.window : p.count_padded) : p.count_padded;
@@ -1602,6 +1605,73 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
             }
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
+        }
+        // ---- a LONG list (more moved nodes than one staging chunk holds): dealt out.  Every wave of the grid takes entry lines of its own,
+        // walks the arc lists of the five nodes a line names (lanes over the arcs) and shifts the arcs wherever they are stored -- atomics at
+        // agent scope, performed where every XCD sees them; then the workgroups meet at a grid-wide barrier, forget what their caches hold of
+        // the reduced costs, and (LD) read their windows again.  The short lists of almost every request keep the barrier-free scheme below
+        // (every workgroup walks every list and shifts only what it reads itself); that scheme read the arc lists 256 times over, which for a
+        // list of 50 000 nodes was 0.9 ms per request.  Not repeatable (shifts are not idempotent): nothing here is retried, a line that has
+        // not arrived yet is waited for.
+        if (cmd != 3u && n_pi > kRcResidentNodes && p.barrier && !prog_header) {
+            const int wave = tid >> 6, lane = tid & 63, waves = nt >> 6;
+            uint32_t failed = 0u;
+            if (blockIdx.x == 0 && wave == 0) {                // the header's moved node
+                const int64_t delta = (int64_t)(((uint64_t)p0_hi << 32) | p0_lo);
+                const int a0 = p.adj_start[p0_node], a1 = p.adj_start[p0_node + 1];
+                for (int f = a0 + lane; f < a1; f += 64) {
+                    const uint32_t x = p.adj[f];
+                    atomicAdd(reinterpret_cast<unsigned long long *>(p.rc + (x & 0x7FFFFFFFu)), (unsigned long long)((x >> 31) ? -delta : delta));
+                }
+                if (lane == 0) {
+                    if (p.narrow) atomicAdd(reinterpret_cast<int32_t *>(p.pi) + p0_node, (int32_t)delta);
+                    else atomicAdd(reinterpret_cast<unsigned long long *>(p.pi) + p0_node, (unsigned long long)delta);
+                }
+            }
+            for (int l = (int)blockIdx.x + wave * (int)gridDim.x; l < lines; l += (int)gridDim.x * waves) {
+                const uint32_t *src = l == 0 ? my_unit + 16 : p.mailbox + (kMailboxTail + (size_t)(l - 1) * 16);
+                v4u x = v4u{0u, 0u, 0u, 0u};
+                const uint64_t t_line = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    if (lane < 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x) : "v"(src + lane * 4) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)::"memory");
+                    if (lane_u32(x[3], 3) == seq) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t_line > p.idle_ticks) { failed = 1u; break; }
+                }
+                if (failed) break;
+#pragma unroll
+                for (int k = 0; k < kMailboxPatchesPerLine; ++k) {
+                    const int e = l * kMailboxPatchesPerLine + k;
+                    if (e >= entries) break;
+                    const uint32_t q0 = lane_u32(x[(3 * k) & 3], (3 * k) >> 2), q1 = lane_u32(x[(3 * k + 1) & 3], (3 * k + 1) >> 2), q2 = lane_u32(x[(3 * k + 2) & 3], (3 * k + 2) >> 2);
+                    if (e < extra_pi) {
+                        const int64_t delta = (int64_t)(((uint64_t)q2 << 32) | q1);
+                        const int a0 = p.adj_start[q0], a1 = p.adj_start[q0 + 1];
+                        for (int f = a0 + lane; f < a1; f += 64) {
+                            const uint32_t y = p.adj[f];
+                            atomicAdd(reinterpret_cast<unsigned long long *>(p.rc + (y & 0x7FFFFFFFu)), (unsigned long long)((y >> 31) ? -delta : delta));
+                        }
+                        if (lane == 0) {
+                            if (p.narrow) atomicAdd(reinterpret_cast<int32_t *>(p.pi) + q0, (int32_t)delta);
+                            else atomicAdd(reinterpret_cast<unsigned long long *>(p.pi) + q0, (unsigned long long)delta);
+                        }
+                    } else if (lane == 0) {
+                        const int a = (int)q0 - p.base;
+                        if ((unsigned)a < (unsigned)p.count_padded) __hip_atomic_store(p.state + a, (int8_t)q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            if (tid == 0 && n_st > 0) { const int a = st_arc0 - p.base; if ((unsigned)a < (unsigned)p.count_padded) __hip_atomic_store(p.state + a, (int8_t)st_val0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (tid == 1 && n_st > 1) { const int a = st_arc1 - p.base; if ((unsigned)a < (unsigned)p.count_padded) __hip_atomic_store(p.state + a, (int8_t)st_val1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            const bool met = grid_barrier();
+            if (__syncthreads_or((int)failed) || !met) {
+                // part of the list is applied and part is not: there is no way back.  The host gets an error, not a wrong answer
+                if (tid == 0 && blockIdx.x == 0) resident_exit(p.exit_word, 4u, served, scan_ticks);
+                return;
+            }
+            if (LD) load_window();
+            prog_header = true;
+            prog_lines = lines;
         }
         // ---- header entries: moved node 0 {node, delta}, state writes 0 and 1
         if (!prog_header) {

@@ -54,7 +54,8 @@ struct mcf_ns {
     bool allow_renumber = false;
     bool seq_walk = true;             // after the first relabelling the big walks go in runs of consecutive ids (MCF_NS_SEQWALK=0: keep the hinted walk)
     double renumber_every = 128.0;    // relabel when the walks since the last relabelling covered this many times the node count
-    double renumber_ticks = 0;
+    double renumber_ticks = 0, renumber_last_ticks = 0, renumber_last_at = 0;
+    bool renumber_forced = false;     // MCF_NS_RENUMBER set: relabel at that interval whatever it costs (tests)
     int64_t sum_supply = 0, art_cost = 0;
     int status = MCF_NOT_SOLVED;
     bool begun = false, transformed = false, prepared = false, solved = false;
@@ -1071,7 +1072,7 @@ int mcf_ns_prepare(mcf_ns *s)
         }
         s->allow_renumber = all;
         s->renumber_every = 128.0;
-        if (const char *u = getenv("MCF_NS_RENUMBER")) { const double v = atof(u); if (v > 0) s->renumber_every = v; }
+        if (const char *u = getenv("MCF_NS_RENUMBER")) { const double v = atof(u); if (v > 0) { s->renumber_every = v; s->renumber_forced = true; } }
         s->seq_walk = !(getenv("MCF_NS_SEQWALK") && getenv("MCF_NS_SEQWALK")[0] == '0');
     }
     s->cands.assign((size_t)std::max(1, s->world), mcf_candidate{0, 0xFFFFFFFFu, -1, 0, 0xFFFFFFFFu, -1});
@@ -1133,13 +1134,18 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         ++it;
         if (it > max_iter) { s->status = MCF_INFEASIBLE; break; }                          // NS.cs:311-317
         if (s->pivot_limit && it > s->pivot_limit) { --it; limited = true; break; }
-        if (s->allow_renumber && (double)s->walked_since_renumber > s->renumber_every * (s->n + 1)) {
+        // ... when the walks since the last time covered renumber_every times the node count, and not more often than it pays: a relabelling
+        // costs the engines a rebuild of their per-node tables (0.3 s with 9 M arcs), so the next one waits 25 times as long as the last one took
+        if (s->allow_renumber && (double)s->walked_since_renumber > s->renumber_every * (s->n + 1) &&
+            (s->renumbers == 0 || s->renumber_forced || ticks() - s->renumber_last_at > 25.0 * s->renumber_last_ticks)) {
             // no search in flight, nothing of a pivot half done: relabel the nodes in thread order, here and in the engines
             const double tr0 = ticks();
             std::vector<int32_t> perm;
             renumber_nodes(s, &perm);
             rc = engines_renumber(s, perm.data());
-            s->renumber_ticks += ticks() - tr0;
+            s->renumber_last_ticks = ticks() - tr0;
+            s->renumber_last_at = ticks();
+            s->renumber_ticks += s->renumber_last_ticks;
             if (rc) break;
         }
         const double t_pot_before = t_pot;

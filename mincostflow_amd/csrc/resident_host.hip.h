@@ -422,6 +422,12 @@ int collect(mcf_engine *e, int grid, Key *out)
         while (!(pair_ready(slots + (size_t)g * stride) && (!dual || pair_ready(slots + (size_t)g * stride + 2)))) {
             _mm_pause();
             if (e->resident_running && (spins & 0xFFF) == 0xFFF && ((const volatile uint32_t *)e->h_exit)[0] != 0) {
+                if (((const volatile uint32_t *)e->h_exit)[0] == 4u) {
+                    (void)hipStreamSynchronize(e->stream);
+                    e->resident_running = false;
+                    resident_slot_release(e);
+                    return mcf::fail(MCF_ERR_TIMEOUT, "the resident grid could not meet at its grid-wide barrier while a list was being applied (are its workgroups all resident?): the device arrays are undefined");
+                }
                 int rc = resident_restart(e);
                 if (rc) return rc;
             }
