@@ -217,6 +217,9 @@ MCF_API int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *a
  * (mcf_engine_bind_potentials) must already be in the new order, and replaces every potential change announced since the last search.
  * Arc ids, states and reduced costs are untouched, so no search result changes.  mcf_engine_can_renumber: 0 for the one layout that
  * orders its arcs by node id (MCF_HIP_BUCKET_NODES). */
+/* Test aid, layouts that keep reduced costs per arc: how many of this engine's stored arcs carry a reduced cost that differs from
+ * cost + pi[source] - pi[target] as the device holds them (0 for the other layouts); *first_arc (optional) = the lowest such arc. */
+MCF_API int mcf_engine_check_reduced_costs(mcf_engine *e, int64_t *mismatches, int32_t *first_arc);
 MCF_API int mcf_engine_can_renumber(mcf_engine *e, int32_t *yes);
 MCF_API int mcf_engine_renumber_nodes(mcf_engine *e, const int32_t *new_of);
 
@@ -440,6 +443,8 @@ MCF_API int mcf_ns_internal(mcf_ns *s, int32_t *search_arc_num, int32_t *arc_cap
  * For tools that study the cycle search (NS.cs:925-1010) on real trees; any pointer may be NULL. */
 MCF_API int mcf_ns_tree(mcf_ns *s, const int32_t **parent, const int32_t **pred_arc, const int32_t **succ_num, const int8_t **pred_dir,
                         const int64_t **flow, const int64_t **upper);
+/* test aid: mcf_engine_check_reduced_costs summed over this solver's engines (after Solve()) */
+MCF_API int mcf_ns_check_reduced_costs(mcf_ns *s, int64_t *mismatches);
 /* what the last mcf_ns_apply_pivot changed: the engine calls a host would make */
 MCF_API int mcf_ns_last_pivot(mcf_ns *s, int32_t *n_state, int32_t arcs[2], int8_t states[2], int32_t *n_nodes,
                               const int32_t **nodes, int64_t *sigma);

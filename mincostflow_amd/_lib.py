@@ -134,6 +134,8 @@ SIGNATURES = {
     "mcf_engine_reload_potentials": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_engine_patch_arcs": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, _i64p]),
     "mcf_engine_can_renumber": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "mcf_engine_check_reduced_costs": (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int32)]),
+    "mcf_ns_check_reduced_costs": (C.c_int, [C.c_void_p, _P(C.c_int64)]),
     "mcf_engine_renumber_nodes": (C.c_int, [C.c_void_p, _i32p]),
     "mcf_engine_find_entering": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
     "mcf_engine_search_begin": (C.c_int, [C.c_void_p]),

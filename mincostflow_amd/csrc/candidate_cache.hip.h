@@ -16,7 +16,7 @@
 // The list is refreshed ASYNCHRONOUSLY: when it runs low the next device search is posted while the host keeps answering from the current
 // list; its answer is installed when it has arrived.  The host only waits for the device when it cannot decide: after a big subtree
 // moved, or when the list ran out above the threshold.
-constexpr int64_t kCandDegreePerNode = 12;      // adjacency entries re-evaluated per pivot at most: this many per node of cand_max_nodes (1152 by default)
+constexpr int64_t kCandDegreePerNode = 8;       // adjacency entries re-evaluated per pivot at most: this many per node of cand_max_nodes (2048 by default)
 constexpr int kCandMaxAvgDegree = 24;           // denser graphs: a single moved node already touches too many arcs
 
 inline const int64_t *cand_pi(const mcf_engine *e) { return e->ext_pi ? e->ext_pi : e->pi.data(); }

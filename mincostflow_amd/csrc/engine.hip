@@ -997,7 +997,8 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
                     e->resident_reg = false;
                     // the grid-wide barrier of that grid (long lists are dealt out, reloads are carried out in the grid): one counter in device memory
                     if (!(getenv("MCF_HIP_RC_BARRIER") && getenv("MCF_HIP_RC_BARRIER")[0] == '0') && hipMalloc((void **)&e->d_barrier, 64) != hipSuccess) { e->d_barrier = nullptr; (void)hipGetLastError(); }
-                    e->rc_list_max = e->d_barrier ? std::min(2 * desc->node_count, std::max(kRcResidentNodes, e->rc_recompute_above)) : kRcResidentNodes;
+                    const bool dealt = e->d_barrier && !(getenv("MCF_HIP_RC_DEALT") && getenv("MCF_HIP_RC_DEALT")[0] == '0');
+                    e->rc_list_max = dealt ? std::min(2 * desc->node_count, std::max(kRcResidentNodes, e->rc_recompute_above)) : kRcResidentNodes;
                 }
                 e->cand_on = !(desc->flags & MCF_ENGINE_NO_CANDIDATES) && !(getenv("MCF_HIP_CANDIDATES") && getenv("MCF_HIP_CANDIDATES")[0] == '0') &&
                              (e->resident_reg || e->rc_mode) && desc->rule == MCF_RULE_BEST_ELIGIBLE && desc->node_count < (1 << 29) &&
@@ -1077,7 +1078,7 @@ void mcf_engine_destroy(mcf_engine *e)
                 e->tk_collect * ns_per_tick / n, e->wait_ticks * ns_per_tick / n, e->heap.size());
     }
     (void)hipSetDevice(e->d.device);
-    if (e->resident_running) (void)resident_stop(e);
+    (void)resident_stop(e);
     if (e->ext_pi && e->ext_pi_pinned) { if (e->stream) (void)hipStreamSynchronize(e->stream); host_unpin(e->ext_pi); }
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->mailbox) hsa_amd_memory_pool_free(e->mailbox);
@@ -1459,6 +1460,37 @@ int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, con
         if (rcr) return rcr;
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
+    return MCF_OK;
+}
+
+int mcf_engine_check_reduced_costs(mcf_engine *e, int64_t *mismatches, int32_t *first_arc)
+{
+    if (!e || !mismatches) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_check_reduced_costs: null argument");
+    *mismatches = 0;
+    if (first_arc) *first_arc = -1;
+    if (!e->rc_mode) return MCF_OK;
+    HIP_TRY(hipSetDevice(e->d.device));
+    int rc = resident_stop(e);
+    if (!rc) rc = flush_pending(e);
+    if (rc) return rc;
+    unsigned long long *d_bad = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_bad, 16));
+    const int big = INT32_MAX;
+    HIP_TRY(hipMemsetAsync(d_bad, 0, 8, e->stream));
+    HIP_TRY(hipMemcpyAsync((char *)d_bad + 8, &big, 4, hipMemcpyHostToDevice, e->stream));
+    const int count = e->end - e->begin, blocks = (count + kThreads - 1) / kThreads;
+    if (count > 0) {
+        if (e->d.int_width == 32) hipLaunchKernelGGL(rc_check_kernel<int32_t>, dim3(blocks), dim3(kThreads), 0, e->stream, e->d_src, e->d_tgt, (const int32_t *)e->d_cost, (const int32_t *)e->d_pi, e->d_rc, count, d_bad, (int *)((char *)d_bad + 8));
+        else hipLaunchKernelGGL(rc_check_kernel<int64_t>, dim3(blocks), dim3(kThreads), 0, e->stream, e->d_src, e->d_tgt, (const int64_t *)e->d_cost, (const int64_t *)e->d_pi, e->d_rc, count, d_bad, (int *)((char *)d_bad + 8));
+    }
+    unsigned long long bad = 0; int first = 0;
+    hipError_t err = hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(&first, (char *)d_bad + 8, 4, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_bad);
+    if (err != hipSuccess) return mcf::fail(MCF_ERR_HIP, "mcf_engine_check_reduced_costs: %s", hipGetErrorString(err));
+    *mismatches = (int64_t)bad;
+    if (first_arc && bad) *first_arc = e->begin + first;
     return MCF_OK;
 }
 

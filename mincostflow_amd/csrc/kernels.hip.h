@@ -1605,6 +1605,13 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
             }
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
+            // These were plain stores: the new reduced costs sit as DIRTY lines in this XCD's L2.  A later long list is dealt out -- workgroups
+            // of other XCDs shift my arcs with atomics performed at memory -- and a dirty line written back afterwards would bury their shifts
+            // (found by mcf_engine_check_reduced_costs on config 5: 206 arcs off after 1.5 M pivots).  Write the L2 back now.
+            // ... and drop the copies: the lines stay in the L2 as clean copies otherwise, the shifts of the next requests are performed
+            // at memory, and a scan that hits such a copy picks a wrong entering arc (seen as four pivots fewer over the whole of config 5).
+            if (tid < 64) asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)\n\tbuffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
         // ---- a LONG list (more moved nodes than one staging chunk holds): dealt out.  Every wave of the grid takes entry lines of its own,
         // walks the arc lists of the five nodes a line names (lanes over the arcs) and shifts the arcs wherever they are stored -- atomics at
@@ -1655,14 +1662,31 @@ __global__ __launch_bounds__(kResidentThreads) void resident_rc_kernel(const Res
                             if (p.narrow) atomicAdd(reinterpret_cast<int32_t *>(p.pi) + q0, (int32_t)delta);
                             else atomicAdd(reinterpret_cast<unsigned long long *>(p.pi) + q0, (unsigned long long)delta);
                         }
-                    } else if (lane == 0) {
-                        const int a = (int)q0 - p.base;
-                        if ((unsigned)a < (unsigned)p.count_padded) __hip_atomic_store(p.state + a, (int8_t)q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
-            if (tid == 0 && n_st > 0) { const int a = st_arc0 - p.base; if ((unsigned)a < (unsigned)p.count_padded) __hip_atomic_store(p.state + a, (int8_t)st_val0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            if (tid == 1 && n_st > 1) { const int a = st_arc1 - p.base; if ((unsigned)a < (unsigned)p.count_padded) __hip_atomic_store(p.state + a, (int8_t)st_val1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            // The State[] writes are NOT dealt: like everywhere in this kernel every workgroup applies all of them with plain stores, so that
+            // every XCD's L2 holds every write (one workgroup writing through to memory would leave the other XCDs' copies of the line stale).
+            // They sit in the entry lines behind the moved nodes.
+            for (int l = extra_pi / kMailboxPatchesPerLine + wave; l < lines && !failed; l += waves) {
+                const uint32_t *src = l == 0 ? my_unit + 16 : p.mailbox + (kMailboxTail + (size_t)(l - 1) * 16);
+                v4u x = v4u{0u, 0u, 0u, 0u};
+                const uint64_t t_line = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    if (lane < 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x) : "v"(src + lane * 4) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)::"memory");
+                    if (lane_u32(x[3], 3) == seq) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t_line > p.idle_ticks) { failed = 1u; break; }
+                }
+                if (failed) break;
+#pragma unroll
+                for (int k = 0; k < kMailboxPatchesPerLine; ++k) {
+                    const int e = l * kMailboxPatchesPerLine + k;
+                    if (e >= extra_pi && e < entries && lane == 0) state_write((int)lane_u32(x[(3 * k) & 3], (3 * k) >> 2), lane_u32(x[(3 * k + 1) & 3], (3 * k + 1) >> 2));
+                }
+            }
+            if (tid == 0 && n_st > 0) state_write(st_arc0, st_val0);
+            if (tid == 1 && n_st > 1) state_write(st_arc1, st_val1);
             const bool met = grid_barrier();
             if (__syncthreads_or((int)failed) || !met) {
                 // part of the list is applied and part is not: there is no way back.  The host gets an error, not a wrong answer
@@ -1842,6 +1866,14 @@ __global__ __launch_bounds__(kThreads) void update_kernel(T *pi, const int32_t *
         const int a = arcs[i] - base;
         if ((unsigned)a < (unsigned)count_padded) state[a] = (int8_t)states[i];
     }
+}
+
+// RC layout, test aid: how many stored arcs' reduced cost differs from cost + pi[source] - pi[target]?
+template <typename T>
+__global__ __launch_bounds__(kThreads) void rc_check_kernel(const int32_t *src, const int32_t *tgt, const T *cost, const T *pi, const int64_t *rc, int count, unsigned long long *bad, int *first)
+{
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < count && rc[i] != (int64_t)cost[i] + (int64_t)pi[src[i]] - (int64_t)pi[tgt[i]]) { atomicAdd(bad, 1ull); atomicMin(first, i); }
 }
 
 // node ids relabelled by the host (mcf_engine_renumber_nodes): the arcs' end points follow; padding arcs (state 0) just get some valid id

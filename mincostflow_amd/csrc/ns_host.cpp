@@ -55,6 +55,7 @@ struct mcf_ns {
     bool seq_walk = true;             // after the first relabelling the big walks go in runs of consecutive ids (MCF_NS_SEQWALK=0: keep the hinted walk)
     double renumber_every = 128.0;    // relabel when the walks since the last relabelling covered this many times the node count
     double renumber_ticks = 0, renumber_last_ticks = 0, renumber_last_at = 0;
+    int64_t renumber_at_pivot = 0;
     bool renumber_forced = false;     // MCF_NS_RENUMBER set: relabel at that interval whatever it costs (tests)
     int64_t sum_supply = 0, art_cost = 0;
     int status = MCF_NOT_SOLVED;
@@ -1114,6 +1115,7 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     s->reload_min = s->reload_min_engines;
     s->walked_since_renumber = 0;
     s->renumber_ticks = 0;
+    s->renumber_at_pivot = 0;
     s->dbg = mcf_ns::Debug{};
     s->dbg.on = getenv("MCF_NS_DEBUG") != nullptr;
     int dbg_class = -1;              // size class of the pivot whose search is being waited for
@@ -1136,7 +1138,10 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         if (s->pivot_limit && it > s->pivot_limit) { --it; limited = true; break; }
         // ... when the walks since the last time covered renumber_every times the node count, and not more often than it pays: a relabelling
         // costs the engines a rebuild of their per-node tables (0.3 s with 9 M arcs), so the next one waits 25 times as long as the last one took
-        if (s->allow_renumber && (double)s->walked_since_renumber > s->renumber_every * (s->n + 1) &&
+        // Locality is not only the walks' business: the cycle searches and the candidate cache's re-evaluation of the moved nodes' arcs chase
+        // the same ids, so a quarter of n pivots since the last time count as well.
+        if (s->dbg.on && (it % 100000) == 0) fprintf(stderr, "[ns] %lld pivots, %.2f s\n", (long long)it, (mcf::now_ns() - t_start) / 1e9);
+        if (s->allow_renumber && ((double)s->walked_since_renumber > s->renumber_every * (s->n + 1) || (!s->renumber_forced && 4 * (it - s->renumber_at_pivot) > (int64_t)s->n)) &&
             (s->renumbers == 0 || s->renumber_forced || ticks() - s->renumber_last_at > 25.0 * s->renumber_last_ticks)) {
             // no search in flight, nothing of a pivot half done: relabel the nodes in thread order, here and in the engines
             const double tr0 = ticks();
@@ -1145,6 +1150,7 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
             rc = engines_renumber(s, perm.data());
             s->renumber_last_ticks = ticks() - tr0;
             s->renumber_last_at = ticks();
+            s->renumber_at_pivot = it;
             s->renumber_ticks += s->renumber_last_ticks;
             if (rc) break;
         }
@@ -1304,6 +1310,17 @@ int mcf_ns_validate(mcf_ns *s, mcf_validation *out)
                               s->flow.data(), s->pi.data());
     if (!rc) rc = mcf_validator_run(v, s->supply_type, total, out);
     mcf_validator_destroy(v);
+    return rc;
+}
+int mcf_ns_check_reduced_costs(mcf_ns *s, int64_t *mismatches)
+{
+    if (!s || !mismatches) return mcf::fail(MCF_ERR_INVALID, "null argument");
+    *mismatches = 0;
+    if (!s->engine) return MCF_OK;
+    int64_t m = 0;
+    int rc = mcf_engine_check_reduced_costs(s->engine, &m, nullptr);
+    *mismatches += m;
+    for (size_t i = 0; i < s->peers.size() && !rc; ++i) { rc = mcf_engine_check_reduced_costs(s->peers[i], &m, nullptr); *mismatches += m; }
     return rc;
 }
 int mcf_ns_get_metrics(mcf_ns *s, mcf_ns_metrics *out)

@@ -350,7 +350,9 @@ void resident_harvest(mcf_engine *e)
 
 int resident_stop(mcf_engine *e)
 {
-    if (!e->resident_running) return MCF_OK;
+    // (a slot taken by a search that was then answered on the host, without a grid ever starting, goes back too: a parked or destroyed
+    // engine must not keep one of the device's few slots)
+    if (!e->resident_running) { resident_slot_release(e); return MCF_OK; }
     if (e->async_posted) {       // a list refresh is on its way: take it in before the grid is told to leave
         const int rc = cand_collect(e, e->async_at);
         if (rc) return rc;

@@ -247,6 +247,9 @@ class NetworkSimplex:
     def get_metrics(self) -> dict:
         m = L.NsMetrics(); L.check(L.lib().mcf_ns_get_metrics(self._h, C.byref(m))); return m.as_dict()
 
+    def check_reduced_costs(self) -> int:
+        m = C.c_int64(); L.check(L.lib().mcf_ns_check_reduced_costs(self._h, C.byref(m))); return m.value
+
     def validate(self) -> dict:                                  # SolutionValidator(graph, solver).Validate()
         v = L.Validation(); L.check(L.lib().mcf_ns_validate(self._h, C.byref(v))); return v.as_dict()
 
@@ -418,6 +421,12 @@ class PivotEngine:
         new_of = _i32(new_of)
         assert new_of.shape == (self.node_count,)
         L.check(L.lib().mcf_engine_renumber_nodes(self._h, new_of))
+
+    def check_reduced_costs(self):
+        """(mismatching arcs, lowest such arc or -1): the per-arc reduced costs of the RC layout against cost + pi[source] - pi[target] on the device."""
+        m, f = C.c_int64(), C.c_int32()
+        L.check(L.lib().mcf_engine_check_reduced_costs(self._h, C.byref(m), C.byref(f)))
+        return m.value, f.value
 
     def patch_arcs(self, arcs, source, target, cost):
         arcs = _i32(arcs)

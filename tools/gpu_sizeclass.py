@@ -20,4 +20,5 @@ for rep in range(1 if which == "config5" else 2):
           f"potential {m['potential_update_us']/it:.2f}; avg subtree {m['potential_nodes']/it:.0f}; device requests {e['resident_requests']} (in-kernel {e['resident_scan_ns']/max(1,e['resident_requests'])/1e3:.2f} us each), "
           f"phases shift/values/scan {e['phase_shift_ns']/max(1,e['resident_requests'])/1e3:.2f}/{e['phase_values_ns']/max(1,e['resident_requests'])/1e3:.2f}/{e['phase_scan_ns']/max(1,e['resident_requests'])/1e3:.2f} us, shift lists {e['shift_lists']}, "
           f"host-decided {e['host_decided']}, resident launches {e['resident_launches']}, update launches {e['update_launches']}, rc recomputes {e['rc_recomputes']}", flush=True)
+    print("reduced costs on the device that differ from cost + pi[s] - pi[t]:", ns.check_reduced_costs(), flush=True)
     del ns
