@@ -82,6 +82,8 @@ MCF_API const char *mcf_last_error(void);
 MCF_API const char *mcf_version(void);
 /* number of visible HIP devices (0 when there is none or the runtime cannot start); never fails */
 MCF_API int mcf_device_count(void);
+/* compute units of a device (0 when it cannot be asked): a resident grid is one workgroup per CU */
+MCF_API int mcf_device_compute_units(int32_t device);
 
 /* ------------------------------------------------------------------------------------------------
  * (1) Engine: entering-arc search + potential update on the device
@@ -330,8 +332,12 @@ MCF_API int mcf_engine_bench_scan(mcf_engine *e, int32_t reps, int32_t cold, int
  * patches (the candidate cache is bypassed by nothing here: an engine with the cache answers from it).  avg/min in ns. */
 MCF_API int mcf_engine_bench_search(mcf_engine *e, int32_t reps, double *avg_ns, double *min_ns);
 
-/* RCCL exchange for sharded engines: one ncclAllGather of 32 bytes per rank per pivot on the engine's stream.
- * id_out/id: the 128-byte ncclUniqueId, created on rank 0 and broadcast by the caller (torch.distributed). */
+/* RCCL exchange for sharded engines: one ncclAllGather per pivot.  A resident engine whose grid leaves at least 8 CUs alone
+ * (desc.resident_workgroups) KEEPS its grid and its candidate cache: the collective runs on a stream of its own and moves 64-byte records
+ * {number, candidate, number} that lie in pinned host memory -- the host writes its own, polls for the others', nothing is copied or
+ * synchronised per pivot.  Any other engine serves its searches with one dispatch each from then on; called without a posted search it
+ * folds the scan's records on the device into the collective's send buffer (rounds 1-2), after mcf_engine_search_begin it exchanges like a
+ * resident one.  id_out/id: the 128-byte ncclUniqueId, created on rank 0 and broadcast by the caller (torch.distributed). */
 MCF_API int mcf_comm_unique_id(uint8_t id_out[128]);
 MCF_API int mcf_engine_comm_init(mcf_engine *e, const uint8_t id[128], int32_t rank, int32_t world);
 /* find_entering_local + all-gather + resolve in one call */

@@ -121,6 +121,7 @@ SIGNATURES = {
     "mcf_last_error": (C.c_char_p, []),
     "mcf_version": (C.c_char_p, []),
     "mcf_device_count": (C.c_int, []),
+    "mcf_device_compute_units": (C.c_int, [C.c_int32]),
     "mcf_engine_create": (C.c_int, [_P(C.c_void_p), _P(EngineDesc)]),
     "mcf_engine_destroy": (None, [C.c_void_p]),
     "mcf_engine_upload": (C.c_int, [C.c_void_p, _i32p, _i32p, _i64p, _i8p, _i64p]),

@@ -158,6 +158,15 @@ struct mcf_engine {
     void *comm = nullptr;
     int rank = 0, world = 1;
     mcf_candidate *d_cand_local = nullptr, *d_cand_all = nullptr, *h_cand_all = nullptr;
+    // the exchange of a RESIDENT engine: 64-byte records {seq, candidate, seq} in pinned host memory that the device sees -- the host writes its
+    // own into x_send, ncclAllGather (on a stream of its own: the engine's stream is held by the resident grid) moves them, the host polls
+    // x_recv until every rank's record carries this exchange's number.  No copy, no stream synchronisation per pivot.
+    struct XRec { uint64_t head; mcf_candidate c; uint64_t pad[2]; uint64_t tail; };
+    XRec *x_send = nullptr, *x_recv = nullptr;
+    void *d_x_send = nullptr, *d_x_recv = nullptr;
+    hipStream_t comm_stream = nullptr;
+    uint64_t x_seq = 0;
+    bool comm_resident = false;
     // resident mode (flag MCF_ENGINE_RESIDENT): mailbox in BAR-mapped fine-grained VRAM, exit record in pinned host memory
     bool resident_ok = false, resident_running = false, resident_reg = false;
     bool has_slot = false;         // this engine's grid occupies one of the device's resident slots (resident_slot_acquire)
@@ -816,6 +825,13 @@ int mcf_device_count(void)
     return n;
 }
 
+int mcf_device_compute_units(int32_t device)
+{
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return cus;
+}
+
 int mcf_shard_range(int32_t m_s, int32_t rank, int32_t world, int32_t *begin, int32_t *end)
 {
     if (world < 1 || rank < 0 || rank >= world || m_s < 0 || !begin || !end) return mcf::fail(MCF_ERR_INVALID, "mcf_shard_range: bad arguments");
@@ -1091,6 +1107,9 @@ void mcf_engine_destroy(mcf_engine *e)
     (void)hipFree(e->d_src); (void)hipFree(e->d_tgt); (void)hipFree(e->d_cost); (void)hipFree(e->d_state); (void)hipFree(e->d_pi);
     (void)hipFree(e->d_cand_local); (void)hipFree(e->d_cand_all); (void)hipFree(e->d_flush); (void)hipFree(e->d_dev_slots);
     if (e->h_cand_all) (void)hipHostFree(e->h_cand_all);
+    if (e->comm_stream) { (void)hipStreamSynchronize(e->comm_stream); (void)hipStreamDestroy(e->comm_stream); }
+    if (e->x_send) (void)hipHostFree(e->x_send);
+    if (e->x_recv) (void)hipHostFree(e->x_recv);
     if (e->h_slots) (void)hipHostFree(e->h_slots);
     for (auto &s : e->stage) {
         if (s.nodes) (void)hipHostFree(s.nodes);
@@ -1873,21 +1892,31 @@ int mcf_engine_comm_init(mcf_engine *e, const uint8_t id[128], int32_t rank, int
     RcclApi *r = rccl();
     if (!r) return mcf::fail(MCF_ERR_COMM, "librccl.so could not be loaded");
     HIP_TRY(hipSetDevice(e->d.device));
-    // the all-gather runs on the engine's stream between the scans: one dispatch per search from here on
     if (int rcs = resident_stop(e)) return rcs;
     if (e->in_flight != mcf_engine::kNoSearch) return mcf::fail(MCF_ERR_STATE, "mcf_engine_comm_init: a search is in flight");
-    if (e->cand_on) {              // the candidate cache lives on the resident grid's answers: hand what it still holds to the device and switch it off
-        if (int rcf = flush_pending(e)) return rcf;
-        e->cand_on = false;
-        e->shift_grid = false;
-        e->st.candidates = 0;
+    // A resident engine keeps its grid and its candidate cache: the collective gets a stream of its own and moves records that lie in pinned
+    // host memory.  Its kernel needs room beside the resident grid, which therefore must leave a few CUs alone (desc.resident_workgroups:
+    // mcf_ns_set_sharding asks for 8 fewer than there are CUs); a grid that fills the device -- and the RC grid's workgroups take whole CUs --
+    // would starve it, so such an engine falls back to one dispatch per search with the exchange on its own stream, as in rounds 1 and 2.
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->d.device);
+    const bool room = e->resident_ok && e->res_grid + 8 <= std::max(cus, 16);
+    const bool keep = room && !(getenv("MCF_HIP_RCCL_RESIDENT") && getenv("MCF_HIP_RCCL_RESIDENT")[0] == '0');
+    if (!keep) {
+        if (e->cand_on) {              // the candidate cache lives on the resident grid's answers: hand what it still holds to the device and switch it off
+            if (int rcf = flush_pending(e)) return rcf;
+            e->cand_on = false;
+            e->shift_grid = false;
+            e->st.candidates = 0;
+        }
+        if (e->resident_ok) {
+            e->resident_ok = false;
+            e->st.resident = 0;
+            e->st.scan_workgroups = e->grid;
+            e->st.scan_threads = e->lds_pi ? kResidentThreads : kThreads;
+        }
     }
-    if (e->resident_ok) {
-        e->resident_ok = false;
-        e->st.resident = 0;
-        e->st.scan_workgroups = e->grid;
-        e->st.scan_threads = e->lds_pi ? kResidentThreads : kThreads;
-    }
+    e->comm_resident = keep;
     Id128 nid;
     memcpy(nid.b, id, 128);
     const int rc = r->comm_init_rank(&e->comm, world, nid, rank);
@@ -1896,6 +1925,17 @@ int mcf_engine_comm_init(mcf_engine *e, const uint8_t id[128], int32_t rank, int
     e->world = world;
     e->st.comm_ranks = world;
     if (r->comm_count) { int seen = 0; if (r->comm_count(e->comm, &seen) == 0) e->st.comm_ranks = seen; }     // as the communicator itself reports it
+    {
+        HIP_TRY(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+        HIP_TRY(hipHostMalloc((void **)&e->x_send, sizeof(mcf_engine::XRec), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostMalloc((void **)&e->x_recv, sizeof(mcf_engine::XRec) * world, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(e->x_send, 0, sizeof(mcf_engine::XRec));
+        memset(e->x_recv, 0, sizeof(mcf_engine::XRec) * world);
+        HIP_TRY(hipHostGetDevicePointer(&e->d_x_send, e->x_send, 0));
+        HIP_TRY(hipHostGetDevicePointer(&e->d_x_recv, e->x_recv, 0));
+        e->x_seq = 0;
+    }
+    if (keep) return MCF_OK;
     HIP_TRY(hipMalloc((void **)&e->d_cand_local, sizeof(mcf_candidate)));
     HIP_TRY(hipMalloc((void **)&e->d_cand_all, sizeof(mcf_candidate) * world));
     HIP_TRY(hipMalloc((void **)&e->d_dev_slots, sizeof(Slot) * kMaxWorkgroups * kSlotStride));
@@ -1908,6 +1948,41 @@ int mcf_engine_find_entering_sharded(mcf_engine *e, int32_t *found, int32_t *arc
     if (!e || !found || !arc) return mcf::fail(MCF_ERR_INVALID, "null argument");
     if (!e->comm) return mcf::fail(MCF_ERR_STATE, "mcf_engine_comm_init has not been called");
     HIP_TRY(hipSetDevice(e->d.device));
+    if (e->comm_resident || e->in_flight != mcf_engine::kNoSearch) {
+        // ---- resident engine (or a search that mcf_engine_search_begin has already posted): its own candidate as usual (from the cache
+        // when the shard's range can be decided on the host, from its grid when not), then the exchange
+        if (e->in_flight == mcf_engine::kNoSearch) { const int rcb = search_begin(e); if (rcb) return rcb; }
+        Key k;
+        int rc = search_end(e, &k);
+        if (rc) return rc;
+        mcf_engine::XRec mine{};
+        key_to_candidate(e, k, &mine.c);
+        const uint64_t xs = ++e->x_seq;
+        mine.head = mine.tail = xs;
+        *e->x_send = mine;
+        std::atomic_thread_fence(std::memory_order_release);
+        const int nrc = rccl()->all_gather(e->d_x_send, e->d_x_recv, sizeof(mcf_engine::XRec), kNcclChar, e->comm, e->comm_stream);
+        if (nrc != 0) return mcf::fail(MCF_ERR_COMM, "ncclAllGather: %s", rccl()->error_string ? rccl()->error_string(nrc) : "error");
+        std::vector<mcf_candidate> all((size_t)e->world);
+        const volatile mcf_engine::XRec *got = e->x_recv;
+        double t0 = 0;
+        for (int r = 0; r < e->world; ++r) {
+            uint64_t spins = 0;
+            while (!(got[r].head == xs && got[r].tail == xs)) {
+                _mm_pause();
+                if ((++spins & 0xFFFFF) == 0) {
+                    const hipError_t q = hipStreamQuery(e->comm_stream);
+                    if (q != hipSuccess && q != hipErrorNotReady) return mcf::fail(MCF_ERR_HIP, "the exchange failed: %s", hipGetErrorString(q));
+                    if (t0 == 0) t0 = mcf::now_ns();
+                    else if (mcf::now_ns() - t0 > 30e9) return mcf::fail(MCF_ERR_TIMEOUT, "rank %d's record of exchange %llu did not arrive within 30 s", r, (unsigned long long)xs);
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            memcpy(&all[r], (const void *)&got[r].c, sizeof(mcf_candidate));
+            if (!(got[r].head == xs && got[r].tail == xs)) { --r; continue; }       // overwritten while it was being read: cannot happen in lock-step, checked anyway
+        }
+        return mcf_engine_resolve(e, e->world, all.data(), found, arc, reduced_cost);
+    }
     // the scan writes its per-workgroup records into device memory and one more workgroup folds them into the all-gather's send buffer:
     // no host poll and no 16-byte copy to the device between the scan and the collective
     e->slots_target = e->d_dev_slots;

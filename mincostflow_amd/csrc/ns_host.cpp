@@ -135,8 +135,7 @@ int engines_reload_potentials(mcf_ns *s, int32_t changed)
 }
 int engines_search_begin(mcf_ns *s)
 {
-    if (s->shard_mode == mcf_ns::kRccl) return MCF_OK;                      // one blocking call (the all-gather runs on the engine's stream)
-    int rc = mcf_engine_search_begin(s->engine);
+    int rc = mcf_engine_search_begin(s->engine);     // (RCCL-sharded engines too: their exchange has a stream of its own; a dispatching one launches its scan here)
     for (size_t i = 0; i < s->peers.size() && !rc; ++i) rc = mcf_engine_search_begin(s->peers[i]);
     return rc;
 }
@@ -1024,7 +1023,11 @@ int mcf_ns_prepare(mcf_ns *s)
             rc = mcf_shard_range(s->search_arcs, s->shard_mode == mcf_ns::kGroup ? r : s->rank, s->world, &dr.shard_begin, &dr.shard_end);
             if (rc) return rc;
         }
-        if (s->shard_mode == mcf_ns::kRccl) dr.flags |= MCF_ENGINE_DISPATCH;      // the RCCL exchange runs on the engine's stream between the scans
+        if (s->shard_mode == mcf_ns::kRccl && dr.resident_workgroups == 0) {
+            // the collective's kernel needs room beside the resident grid: leave one CU per XCD alone (mcf_engine_comm_init checks)
+            const int cus = mcf_device_compute_units(dr.device);
+            if (cus >= 64) dr.resident_workgroups = cus - 8;
+        }
         if (s->shard_mode == mcf_ns::kGroup) {
             dr.device = s->group_devices[r];
             const int sharing = (int)std::count(s->group_devices.begin(), s->group_devices.end(), dr.device);

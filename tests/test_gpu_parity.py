@@ -354,9 +354,9 @@ def test_sharded_engines_resolve_like_one_engine(rule, optimized, vw):
 
 @pytest.mark.parametrize("layout", ["lds-potentials", "gathering", "rc"])
 def test_sharded_solve_through_the_rccl_exchange(layout, monkeypatch):
-    """mcf_ns_set_sharding + mcf_engine_find_entering_sharded on the one GPU of this box (world size 1: the scan's records are folded on the
-    device into the all-gather's send buffer, the all-gather and the MINLOC still run); more ranks are covered by tests/test_sharded_gloo.py
-    and the same-device shard tests.  Every rule, and each of the three dispatch kernels (potentials in LDS, gathered, RC layout)."""
+    """mcf_ns_set_sharding + mcf_engine_find_entering_sharded on the one GPU of this box (world size 1: the shard engine stays resident with
+    its candidate cache, its candidate goes through ncclAllGather on a stream of its own and the MINLOC still runs); more ranks are covered by
+    tests/test_sharded_gloo.py and the same-device shard tests.  Every rule, on each of the three layouts (potentials in LDS, in registers, RC)."""
     if layout == "rc":
         monkeypatch.setenv("MCF_HIP_RC", "1")
     if layout == "lds-potentials":
@@ -376,7 +376,10 @@ def test_sharded_solve_through_the_rccl_exchange(layout, monkeypatch):
         assert ns.solve() == st_o == 1
         assert np.array_equal(ns.trace(), tr_o) and ns.get_total_cost() == o.total_cost
         e = ns.get_metrics()["engine"]
-        assert e["resident"] == 0 and e["comm_ranks"] == 1        # the exchange needs the stream: one dispatch per search
+        # the engine keeps its resident grid and, for Best Eligible on these sparse graphs, its candidate cache: the collective runs on a
+        # stream of its own over records in pinned host memory
+        assert e["resident"] == 1 and e["comm_ranks"] == 1 and e["resident_requests"] > 0
+        assert e["candidates"] == (1 if rule == O.RULE_BEST else 0) and (rule != O.RULE_BEST or e["host_decided"] > 0)
         assert e["rc_layout"] == (1 if layout == "rc" else 0)
 
 
