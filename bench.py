@@ -39,7 +39,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
 SEED = 13502460
-TRAFFIC_FILE = "traffic_r02.json"   # PMC FETCH_SIZE of a separate rocprofv3 --pmc pass (gpurun refuses --pmc beside tracing)
+TRAFFIC_FILE = "traffic_r03.json"   # PMC FETCH_SIZE of a separate rocprofv3 --pmc pass (gpurun refuses --pmc beside tracing)
 
 
 def parse():
@@ -92,6 +92,7 @@ def cpu_baseline(g, rule, budget_s, reference_default=False, vector_width=VECTOR
     vector_width: Vector<long>.Count of the machine whose optimized Block Search is reproduced (4 = x64: a boundary hit in the "SIMD" part
     scans on to the end of the range; 0 = not hardware accelerated: stop at the block boundary).  Only that rule reads it."""
     from oracle import ns_oracle as O
+    core = pin_to_one_core()
     p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
     if reference_default:
         o = O.Oracle(p, O.SEM_CSHARP, {0: O.RULE_FIRST, 1: O.RULE_BEST, 2: O.RULE_BLOCK}[rule], auto_config=True)
@@ -110,11 +111,27 @@ def cpu_baseline(g, rule, budget_s, reference_default=False, vector_width=VECTOR
     sample = (f"whole solve ({done} pivots)" if ended else f"first {done} pivots of the same solve") + f", {dt:.1f} s of CPU work"
     return {"value": done / dt, "unit": "pivots/s", "cores": 1, "kind": "port", "sample": sample,
             "semantics": "plain rule, auto-configured" if reference_default else f"EnableOptimizedPivot(true), Vector<long>.Count = {vector_width}" + (" (not hardware accelerated)" if vector_width == 0 else ""),
-            "pinned_to_cpu": sorted(os.sched_getaffinity(0)) if len(os.sched_getaffinity(0)) <= 4 else f"{len(os.sched_getaffinity(0))} cpus allowed",
+            "pinned_to_cpu": core,
             "host_cores_available": os.cpu_count(), "host_cpu": cpu_model(), "us_per_pivot": dt / max(done, 1) * 1e6,
             "phase_us_per_pivot": {"pivot_search": ph[0] / max(done, 1), "tree_update": ph[1] / max(done, 1), "potential_update": ph[2] / max(done, 1)},
             "solve_ms_if_whole": dt * 1e3 if ended else None,
             "not_timed": "LEMON (needs its CMake-generated config.h: unbuildable here) and the C# reference (no .NET toolchain in the image)"}
+
+
+_PINNED = None
+
+
+def pin_to_one_core():
+    """The CPU legs run on ONE core (the reference is single-threaded): the core this thread is on when the first of them starts.  Returns its number."""
+    global _PINNED
+    if _PINNED is None:
+        try:
+            here = os.sched_getcpu()
+            os.sched_setaffinity(0, {here})
+            _PINNED = here
+        except (AttributeError, OSError):
+            _PINNED = -1
+    return _PINNED
 
 
 def other_config(M, name, local_rank, cpu_seconds):
@@ -236,10 +253,10 @@ def microbench():
     rng = np.random.default_rng(7)
     out = []
 
-    def run(label, n_nodes, m_s, src, tgt, cost, state, pi, endpoints, env=None):
+    def run(label, n_nodes, m_s, src, tgt, cost, state, pi, endpoints, env=None, width=64):
         for k, v in (env or {}).items():
             os.environ[k] = str(v)
-        eng = M.PivotEngine(n_nodes, m_s, m_s, rule=M.PivotRule.BestEligible, int_width=64, flags=M.ENGINE_DISPATCH)
+        eng = M.PivotEngine(n_nodes, m_s, m_s, rule=M.PivotRule.BestEligible, int_width=width, flags=M.ENGINE_DISPATCH)
         for k in (env or {}):
             os.environ.pop(k, None)
         eng.upload(src, tgt, cost, state, pi)
@@ -248,7 +265,7 @@ def microbench():
         nbytes = st["scan_bytes_read"]             # what this layout's scan has to read (9 B per arc in the RC layout: no potential gathers)
         warm = eng.bench_scan(reps=20)
         cold = eng.bench_scan(reps=8, cold=True, flush_bytes=512 << 20)
-        out.append({"case": label, "arcs": m_s, "nodes": n_nodes, "dtype": "i64", "endpoints": endpoints,
+        out.append({"case": label, "arcs": m_s, "nodes": n_nodes, "dtype": f"i{width}", "endpoints": endpoints,
                     "layout": "reduced costs kept per arc (RC): state + reduced cost streamed, nothing gathered" if st["rc_layout"] else
                               ("potentials in LDS" if n_nodes <= 16384 else "SoA arcs + two potential gathers per arc"),
                     "bytes": nbytes, "survey_bytes": survey,
@@ -263,9 +280,13 @@ def microbench():
                           ("8M arcs, uniform random end points over 1M nodes", 8_000_000, 1_000_001),
                           ("dense (assignment-like), potentials fit LDS", 64_000_000, 2_001),
                           ("uniform random end points over 1M nodes (gather worst case)", 64_000_000, 1_000_001)):
-        run(label, n, m_s, rng.integers(0, n, m_s, dtype=np.int32), rng.integers(0, n, m_s, dtype=np.int32),
-            rng.integers(-10 ** 4, 10 ** 4, m_s, dtype=np.int64), rng.integers(-1, 2, m_s, dtype=np.int8),
-            rng.integers(-10 ** 9, 1, n, dtype=np.int64), "uniform random")
+        arrs = (rng.integers(0, n, m_s, dtype=np.int32), rng.integers(0, n, m_s, dtype=np.int32),
+                rng.integers(-10 ** 4, 10 ** 4, m_s, dtype=np.int64), rng.integers(-1, 2, m_s, dtype=np.int8),
+                rng.integers(-10 ** 9, 1, n, dtype=np.int64))
+        run(label, n, m_s, *arrs, "uniform random")
+        # the same arrays with 32-bit costs and potentials on the device (13 B per arc + 4 B per node; SURVEY.md 8d asks for both widths)
+        run(label, n, m_s, *arrs, "uniform random", width=32)
+        del arrs
     # BASELINE.json configs[4] as generated: arcs grouped by tail node, random heads
     g5 = M.netgen_like(SEED, 1_000_000, 8_000_000, 1000, 1000)
     ns5 = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible)
@@ -360,6 +381,48 @@ def large_instance_sample(M, local_rank, with_cpu, gpu_pivots=3000, cpu_seconds=
         out["pivots_identical_to_cpu_port"] = {"checked": min(150, len(gpu_trace)), "identical": same}
         assert same == min(150, len(gpu_trace)), "the GPU run's pivots differ from the CPU port's"
     return out
+
+
+def potential_update_microbench(M, g3, local_rank):
+    """the potential update against its bytes -- 20 per node of a list (12 with 32-bit potentials) for update_kernel; where
+    reduced costs are kept per arc, update_rc_kernel also walks the nodes' arc lists (8 per node + 20 per arc-list entry).  Lists of distinct nodes
+    spread over the whole table; HIP events around every launch (mcf_engine_bench_update)."""
+    import numpy as np
+    out = []
+
+    def one(label, kernel, node_count, m_s, arrs, width, counts, env=None):
+        for k, v in (env or {}).items():
+            os.environ[k] = str(v)
+        eng = M.PivotEngine(node_count, m_s, m_s, rule=M.PivotRule.BestEligible, int_width=width, device=local_rank, flags=M.ENGINE_DISPATCH)
+        for k in (env or {}):
+            os.environ.pop(k, None)
+        eng.upload(*arrs)
+        for cnt in counts:
+            avg, mn, nb = eng.bench_update(min(cnt, node_count), reps=20)
+            out.append({"case": label, "kernel": kernel, "dtype": f"i{width}", "nodes_in_list": min(cnt, node_count), "bytes": nb, "avg_us": avg / 1e3, "min_us": mn / 1e3,
+                        "achieved_GBps": nb / avg, "frac_of_hbm_peak": nb / avg / HBM_PEAK_GBS})
+        del eng
+
+    ns3 = M.NetworkSimplex.from_problem(g3).set_pivot_rule(M.PivotRule.BestEligible)
+    assert ns3.begin() == 0
+    it = ns3.internal(); ms = it["search_arc_num"]
+    arrs3 = (it["source"][:ms], it["target"][:ms], it["cost"][:ms], it["state"][:ms], it["pi"])
+    one("config-3 arrays", "update_kernel<int64>", g3.node_count + 1, ms, arrs3, 64, (1_000, 16_000, 100_000))
+    g2 = M.netgen_like(SEED, 10_000, 30_000, 100, 100)
+    ns2 = M.NetworkSimplex.from_problem(g2).set_pivot_rule(M.PivotRule.BlockSearch)
+    assert ns2.begin() == 0
+    it2 = ns2.internal(); ms2 = it2["search_arc_num"]
+    one("config-2 arrays", "update_kernel<int32>", g2.node_count + 1, ms2, (it2["source"][:ms2], it2["target"][:ms2], it2["cost"][:ms2], it2["state"][:ms2], it2["pi"]), 32, (1_000, 10_000))
+    g5 = M.netgen_like(SEED, 1_000_000, 8_000_000, 1000, 1000)
+    ns5 = M.NetworkSimplex.from_problem(g5).set_pivot_rule(M.PivotRule.BestEligible)
+    assert ns5.begin() == 0
+    it5 = ns5.internal(); ms5 = it5["search_arc_num"]
+    arrs5 = (it5["source"][:ms5], it5["target"][:ms5], it5["cost"][:ms5], it5["state"][:ms5], it5["pi"])
+    one("config-5 arrays, gathering layout", "update_kernel<int64>", g5.node_count + 1, ms5, arrs5, 64, (64_000, 1_000_000), env={"MCF_HIP_RC": 0})
+    one("config-5 arrays, reduced costs kept per arc", "update_rc_kernel<int64>", g5.node_count + 1, ms5, arrs5, 64, (1_000, 64_000, 500_000))
+    return {"rows": out,
+            "note": "a list of k nodes is k scattered 8-byte updates into a table of up to 8 MB: at the sizes a pivot produces these are launch-latency-bound kernels "
+                    "(an empty dispatch measures ~4 us by this method); the resident grids apply their lists inside the grid instead (in_kernel_phases_us)"}
 
 
 def hbm_probe():
@@ -561,7 +624,14 @@ def main():
         if e[0]["candidates"]:
             variant = ("REG, LPI, CAND" if lds else "REG, CAND") + " (candidate list per search)"
         kernel_name = f"resident_kernel<int{width}, {rule_name}, {variant}>"
+        if e[0].get("shift_grid"):
+            kernel_name = f"resident_cand_kernel<int{width}, 2 tiles> (Best Eligible + candidate list; arcs and end-point potentials in registers, patched straight from the request)"
         extra = {"launches": launches, "requests_per_launch": requests / max(launches, 1), "avg_launch_ms": avg_launch_ns / 1e6,
+                 "in_kernel_phases_us": {"fetch_lines_and_set_bits": sum(x["phase_shift_ns"] for x in e) / max(requests, 1) / 1e3,
+                                         "apply_values_and_states": sum(x["phase_values_ns"] for x in e) / max(requests, 1) / 1e3,
+                                         "evaluate_reduce_publish": sum(x["phase_scan_ns"] for x in e) / max(requests, 1) / 1e3,
+                                         "shift_lists": sum(x["shift_lists"] for x in e)} if e[0].get("shift_grid") else None,
+                 "node_relabellings_per_solve": sum(x["renumberings"] for x in e) / len(e),
                  "in_kernel": {"avg_request_us": in_kernel_ns / 1e3, "achieved": bytes_per_scan / in_kernel_ns if in_kernel_ns > 0 else 0.0,
                                "frac": bytes_per_scan / in_kernel_ns / HBM_PEAK_GBS if in_kernel_ns > 0 else 0.0,
                                "what": "device clock (s_memrealtime), workgroup 0: request seen -> 16-byte record published; includes fetching and applying the patch list"}}
@@ -647,19 +717,24 @@ def main():
         def shared_solver():
             ns = M.NetworkSimplex.from_problem(g).set_pivot_rule(rule).enable_optimized_pivot(True)
             return ns.set_device(local_rank, width, 0, M.ENGINE_SHARE_DEVICE).prepare()
-        cs = [shared_solver() for _ in range(args.concurrent)]
-        torch.cuda.synchronize()
-        tc = time.perf_counter()
-        th = [threading.Thread(target=x.solve) for x in cs]
-        [t_.start() for t_ in th]
-        [t_.join() for t_ in th]
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - tc
-        pv = sum(x.get_metrics()["iterations"] for x in cs)
-        assert all(x.status == M.SolverStatus.Optimal and x.get_total_cost() == cost for x in cs)
-        line["concurrent_solves_one_gpu"] = {"solves_in_flight": args.concurrent, "pivots_per_s": pv / dt, "seconds": dt,
-                                             "solve_ms_each": sum(x.get_metrics()["loop_us"] for x in cs) / len(cs) / 1e3}
-        del cs
+        conc = {}
+        for k_in_flight in sorted({2, 3, args.concurrent}):
+            cs = [shared_solver() for _ in range(k_in_flight)]
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            th = [threading.Thread(target=x.solve) for x in cs]
+            [t_.start() for t_ in th]
+            [t_.join() for t_ in th]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - tc
+            pv = sum(x.get_metrics()["iterations"] for x in cs)
+            assert all(x.status == M.SolverStatus.Optimal and x.get_total_cost() == cost for x in cs)
+            conc[str(k_in_flight)] = {"solves_in_flight": k_in_flight, "pivots_per_s": pv / dt, "seconds": dt,
+                                      "solve_ms_each": sum(x.get_metrics()["loop_us"] for x in cs) / len(cs) / 1e3}
+            del cs
+        line["concurrent_solves_one_gpu"] = dict(conc[str(args.concurrent)], by_solves_in_flight=conc,
+                                                 note="one host thread and one resident grid per solve (MCF_ENGINE_SHARE_DEVICE: the small-footprint grid); three such grids fit a CU, "
+                                                      "a fourth waits for CUs until another solve ends -- a single solve is a host <-> device latency chain, so this is what the idle device buys")
     if not args.no_cpu_baseline and args.gpus == 1:
         line["cpu_baseline"] = cpu_baseline(g, rule, args.cpu_seconds)
         if rule != M.PivotRule.BlockSearch:
@@ -701,6 +776,7 @@ def main():
                 "frac": x["cold_frac_of_hbm_peak"], "frac_warm": x["warm_frac_of_hbm_peak"], "traffic": tr,
                 "traffic_source": f"profiles/{TRAFFIC_FILE} (separate rocprofv3 --pmc FETCH_SIZE pass)" if tr else None}
     if not args.no_microbench and args.gpus == 1:
+        line["potential_update_microbench"] = potential_update_microbench(M, g, local_rank)
         line["large_instance_sample"] = large_instance_sample(M, local_rank, not args.no_cpu_baseline)
     if not args.no_validator and args.gpus == 1:
         line["solution_validator"] = validator_bench(M, g, solvers[0], local_rank, not args.no_cpu_baseline)

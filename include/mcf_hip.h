@@ -328,6 +328,12 @@ MCF_API int mcf_engine_reset_stats(mcf_engine *e);
 MCF_API int mcf_engine_bench_scan(mcf_engine *e, int32_t reps, int32_t cold, int64_t flush_bytes,
                                   double *avg_ns, double *min_ns);
 
+/* Potential-update micro-benchmark (20 bytes per node of a list; 12 with 32-bit potentials): the update kernel that dispatch
+ * mode runs for long lists -- update_kernel, or update_rc_kernel where reduced costs are kept per arc (then the list's nodes' arc lists are
+ * walked and shifted too: + 8 bytes per node for its list bounds and 20 per arc-list entry) -- over `count` distinct nodes, `reps` launches
+ * each timed with HIP events.  *bytes = algorithmic bytes of one launch.  The engine's arrays are unchanged when the call returns. */
+MCF_API int mcf_engine_bench_update(mcf_engine *e, int32_t count, int32_t reps, double *avg_ns, double *min_ns, int64_t *bytes);
+
 /* Whole-search micro-benchmark: host wall time from posting / launching a search to its merged answer, `reps` times back to back without
  * patches (the candidate cache is bypassed by nothing here: an engine with the cache answers from it).  avg/min in ns. */
 MCF_API int mcf_engine_bench_search(mcf_engine *e, int32_t reps, double *avg_ns, double *min_ns);

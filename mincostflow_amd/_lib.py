@@ -165,6 +165,7 @@ SIGNATURES = {
     "mcf_engine_reset_stats": (C.c_int, [C.c_void_p]),
     "mcf_engine_bench_scan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, _P(C.c_double), _P(C.c_double)]),
     "mcf_engine_bench_search": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_double), _P(C.c_double)]),
+    "mcf_engine_bench_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_double), _P(C.c_double), _P(C.c_int64)]),
     "mcf_comm_unique_id": (C.c_int, [_u8p]),
     "mcf_engine_comm_init": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32]),
     "mcf_engine_find_entering_sharded": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),

@@ -133,6 +133,7 @@ struct mcf_engine {
     bool ext_pi_pinned = false;        // the bound array is registered with HIP (the device can copy it by itself): mcf_engine_reload_potentials
     const int64_t *d_ext_pi = nullptr; // ... and this is where the device sees it: the resident RC grid copies it itself (cmd 3), no stop
     uint32_t *d_barrier = nullptr;     // counter of that grid's grid-wide barrier
+    int32_t *d_node_map = nullptr;     // mcf_engine_renumber_nodes: the permutation on the device (kept between calls)
     bool reload_pi = false;            // the whole bound array is to be copied to the device before the next search (and the RC layout recomputed)
     const int64_t *ext_pi = nullptr;   // mcf_engine_bind_potentials: the caller's own array is read instead of the mirror (no second copy to keep up to date)
     int64_t max_abs_cost = 0;
@@ -1103,7 +1104,7 @@ void mcf_engine_destroy(mcf_engine *e)
     if (e->res_stop) (void)hipEventDestroy(e->res_stop);
     if (e->comm && rccl() && rccl()->comm_destroy) rccl()->comm_destroy(e->comm);
     if (e->d_orig) (void)hipFree(e->d_orig);
-    (void)hipFree(e->d_rc); (void)hipFree(e->d_adj_start); (void)hipFree(e->d_adj); (void)hipFree(e->d_barrier);
+    (void)hipFree(e->d_rc); (void)hipFree(e->d_adj_start); (void)hipFree(e->d_adj); (void)hipFree(e->d_barrier); (void)hipFree(e->d_node_map);
     (void)hipFree(e->d_src); (void)hipFree(e->d_tgt); (void)hipFree(e->d_cost); (void)hipFree(e->d_state); (void)hipFree(e->d_pi);
     (void)hipFree(e->d_cand_local); (void)hipFree(e->d_cand_all); (void)hipFree(e->d_flush); (void)hipFree(e->d_dev_slots);
     if (e->h_cand_all) (void)hipHostFree(e->h_cand_all);
@@ -1516,7 +1517,10 @@ int mcf_engine_check_reduced_costs(mcf_engine *e, int64_t *mismatches, int32_t *
 int mcf_engine_can_renumber(mcf_engine *e, int32_t *yes)
 {
     if (!e || !yes) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_can_renumber: null argument");
-    *yes = e->bucket_nodes > 0 ? 0 : 1;          // the bucketed layout orders its arcs by target id
+    // not the bucketed layout (it orders its arcs by target id); and not an engine that shares its device with other solvers' grids: a
+    // relabelling stops and restarts the resident grid, and a grid that comes back while the CUs are full of the others' workgroups waits for
+    // them -- four solves in flight fell from 350 k to 190 k pivots/s together when their grids kept leaving and re-entering
+    *yes = (e->bucket_nodes > 0 || (e->d.flags & MCF_ENGINE_SHARE_DEVICE)) ? 0 : 1;
     return MCF_OK;
 }
 
@@ -1547,16 +1551,15 @@ int mcf_engine_renumber_nodes(mcf_engine *e, const int32_t *new_of)
     rc = flush_pending(e);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    // device: end points, potentials
-    int32_t *d_map = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_map, sizeof(int32_t) * (size_t)n));
-    hipError_t err = hipMemcpy(d_map, new_of, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice);
+    // device: end points, potentials.  (The map's buffer is kept: hipMalloc / hipFree synchronise the whole device, and other solvers' resident
+    // grids on it only leave when their solves end -- four solves in flight took 2.9 s each instead of 0.8 while this allocated per call.)
+    if (!e->d_node_map) HIP_TRY(hipMalloc((void **)&e->d_node_map, sizeof(int32_t) * (size_t)n));
+    hipError_t err = hipMemcpyAsync(e->d_node_map, new_of, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, e->stream);
     if (err == hipSuccess) {
-        hipLaunchKernelGGL(renumber_kernel, dim3(e->count_padded / kThreads), dim3(kThreads), 0, e->stream, e->d_src, e->d_tgt, d_map, e->count_padded);
+        hipLaunchKernelGGL(renumber_kernel, dim3(e->count_padded / kThreads), dim3(kThreads), 0, e->stream, e->d_src, e->d_tgt, e->d_node_map, e->count_padded);
         err = hipGetLastError();
     }
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
-    (void)hipFree(d_map);
     if (err != hipSuccess) return mcf::fail(MCF_ERR_HIP, "mcf_engine_renumber_nodes: %s", hipGetErrorString(err));
     if (!e->ext_pi) {
         if (!e->mirror_valid) { rc = mcf_engine_download_pi(e, e->pi.data()); if (rc) return rc; e->mirror_valid = true; }
@@ -1569,9 +1572,11 @@ int mcf_engine_renumber_nodes(mcf_engine *e, const int32_t *new_of)
         if (e->d.int_width == 32) {
             std::vector<int32_t> p32((size_t)n);
             for (int u = 0; u < n; ++u) { if (!fits32(pi[u])) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d does not fit int32", u); p32[u] = (int32_t)pi[u]; }
-            HIP_TRY(hipMemcpy(e->d_pi, p32.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpyAsync(e->d_pi, p32.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
         } else {
-            HIP_TRY(hipMemcpy(e->d_pi, pi, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpyAsync(e->d_pi, pi, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
         }
     }
     // host mirrors of the candidate cache
@@ -1845,6 +1850,74 @@ int mcf_engine_bench_scan(mcf_engine *e, int32_t reps, int32_t cold, int64_t flu
     (void)hipEventDestroy(b);
     *avg_ns = sum / reps;
     *min_ns = mn;
+    return MCF_OK;
+}
+
+// The potential update as a kernel of its own (what dispatch mode runs for lists that do not fit the scan's arguments, and what a stopped
+// resident grid's engine falls back to): `count` distinct nodes get new values, `reps` times, each launch timed with HIP events on the
+// engine's stream.  update_kernel moves 20 bytes per node (index 4, value 8 read; potential 8 written; 12 with 32-bit potentials);
+// update_rc_kernel additionally walks the node's arc list (4 bytes per entry) and shifts each arc's reduced cost (8 read + 8 written).
+// The values alternate between +1 and back, so the engine's state is what it was when the call returns (reps is rounded up to even).
+int mcf_engine_bench_update(mcf_engine *e, int32_t count, int32_t reps, double *avg_ns, double *min_ns, int64_t *bytes)
+{
+    if (!e || count < 1 || count > e->d.node_count || reps < 1 || !avg_ns || !min_ns) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_bench_update: bad arguments");
+    if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
+    HIP_TRY(hipSetDevice(e->d.device));
+    int rc = resident_stop(e);
+    if (!rc) rc = flush_pending(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const int n = e->d.node_count;
+    std::vector<int64_t> cur((size_t)n);
+    rc = mcf_engine_download_pi(e, cur.data());
+    if (rc) return rc;
+    // every (n / count)-th node: distinct, spread over the whole table
+    std::vector<int32_t> nodes((size_t)count);
+    const int64_t stride = std::max<int64_t>(1, n / count);
+    for (int i = 0; i < count; ++i) nodes[i] = (int32_t)((i * stride) % n);
+    std::sort(nodes.begin(), nodes.end());
+    nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
+    const int k = (int)nodes.size();
+    int32_t *d_nodes = nullptr; int64_t *d_vals[2] = {nullptr, nullptr};
+    HIP_TRY(hipMalloc((void **)&d_nodes, sizeof(int32_t) * k));
+    HIP_TRY(hipMalloc((void **)&d_vals[0], sizeof(int64_t) * k));
+    HIP_TRY(hipMalloc((void **)&d_vals[1], sizeof(int64_t) * k));
+    std::vector<int64_t> v0((size_t)k), v1((size_t)k);
+    int64_t degree = 0;
+    for (int i = 0; i < k; ++i) {
+        v0[i] = cur[nodes[i]]; v1[i] = cur[nodes[i]] + (e->d.int_width == 32 && cur[nodes[i]] == INT32_MAX ? -1 : 1);
+        if (e->rc_mode) degree += e->h_adj_start[nodes[i] + 1] - e->h_adj_start[nodes[i]];
+    }
+    HIP_TRY(hipMemcpy(d_nodes, nodes.data(), sizeof(int32_t) * k, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_vals[0], v0.data(), sizeof(int64_t) * k, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_vals[1], v1.data(), sizeof(int64_t) * k, hipMemcpyHostToDevice));
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    const int blocks = (k + kThreads - 1) / kThreads;
+    const int rounds = (reps + 1) / 2 * 2;
+    double sum = 0, mn = 1e30;
+    for (int r = 0; r < rounds; ++r) {
+        const int64_t *vals = d_vals[(r + 1) & 1];          // +1 first, back second
+        const dim3 grid(blocks), block(kThreads);
+        if (e->rc_mode && e->d.int_width == 32) hipExtLaunchKernelGGL(update_rc_kernel<int32_t>, grid, block, 0, e->stream, a, b, 0, (int32_t *)e->d_pi, (const int32_t *)d_nodes, vals, k, e->d_state, (const int32_t *)nullptr, (const int32_t *)nullptr, 0, e->begin, e->count_padded, e->d_rc, e->d_adj_start, e->d_adj);
+        else if (e->rc_mode) hipExtLaunchKernelGGL(update_rc_kernel<int64_t>, grid, block, 0, e->stream, a, b, 0, (int64_t *)e->d_pi, (const int32_t *)d_nodes, vals, k, e->d_state, (const int32_t *)nullptr, (const int32_t *)nullptr, 0, e->begin, e->count_padded, e->d_rc, e->d_adj_start, e->d_adj);
+        else if (e->d.int_width == 32) hipExtLaunchKernelGGL(update_kernel<int32_t>, grid, block, 0, e->stream, a, b, 0, (int32_t *)e->d_pi, (const int32_t *)d_nodes, vals, k, e->d_state, (const int32_t *)nullptr, (const int32_t *)nullptr, 0, e->begin, e->count_padded);
+        else hipExtLaunchKernelGGL(update_kernel<int64_t>, grid, block, 0, e->stream, a, b, 0, (int64_t *)e->d_pi, (const int32_t *)d_nodes, vals, k, e->d_state, (const int32_t *)nullptr, (const int32_t *)nullptr, 0, e->begin, e->count_padded);
+        hipError_t err = hipGetLastError();
+        if (err == hipSuccess) err = hipEventSynchronize(b);
+        float ms = 0.f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, a, b);
+        if (err != hipSuccess) { (void)hipFree(d_nodes); (void)hipFree(d_vals[0]); (void)hipFree(d_vals[1]); return mcf::fail(MCF_ERR_HIP, "mcf_engine_bench_update: %s", hipGetErrorString(err)); }
+        sum += ms * 1e6;
+        mn = std::min(mn, (double)ms * 1e6);
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(d_nodes); (void)hipFree(d_vals[0]); (void)hipFree(d_vals[1]);
+    *avg_ns = sum / rounds;
+    *min_ns = mn;
+    if (bytes) *bytes = (int64_t)k * (e->d.int_width == 64 ? 20 : 12) + (e->rc_mode ? (int64_t)k * 8 + degree * 20 : 0);
     return MCF_OK;
 }
 

@@ -52,6 +52,7 @@ struct mcf_ns {
     std::vector<int32_t> new_of, orig_of;
     int64_t walked_since_renumber = 0, jumps_since_renumber = 0, renumbers = 0;
     bool allow_renumber = false;
+    bool fused_cycle_search = true;   // find_join + find_leaving in one climb (MCF_NS_FUSED_CYCLE=0: two climbs, as the reference does it)
     bool seq_walk = true;             // after the first relabelling the big walks go in runs of consecutive ids (MCF_NS_SEQWALK=0: keep the hinted walk)
     double renumber_every = 128.0;    // relabel when the walks since the last relabelling covered this many times the node count
     double renumber_ticks = 0, renumber_last_ticks = 0, renumber_last_at = 0;
@@ -639,6 +640,66 @@ void restore_node_ids(mcf_ns *s)
     s->new_of.clear(); s->orig_of.clear();
 }
 
+// find_join + find_leaving in ONE climb.  The reference climbs twice: first to the join node (NS.cs:925-941: whichever side has the smaller
+// SuccNum steps up), then from both end points of the entering arc to the join again, taking the minimum residual of each path (NS.cs:943-1010).
+// Both climbs visit the same nodes in the same bottom-up order per side, and the second one only needs to know where each side stops -- which
+// the first one discovers as it goes.  So the residuals are folded into the first climb: a step on the FIRST path (the side the entering arc's
+// state makes "first") compares with '<', a step on the second with '<=', exactly as NS.cs:957-997 -- with one difference in ORDER: the
+// reference finishes the first path before it starts the second, here the two interleave.  That matters for ties between the paths: the
+// reference lets a second-path arc with residual EQUAL to the first path's minimum win (d <= delta), whenever it comes.  Interleaved, each
+// side keeps its own minimum and the two are combined at the end with the same rule (second path wins ties), which is the same arc:
+//   first-path winner  = the lowest node u on it with residual < everything below it      (strict: the first among equals, bottom-up)
+//   second-path winner = the highest node u on it with residual <= everything below it and <= the first path's minimum (the last among equals)
+// and the second path's own '<=' chain must be evaluated against min(first-path minimum, running): since min is associative the result
+// is: delta = min(d1, d2); leaving = second-path's LAST node with d == d2 if d2 <= d1, else first-path's FIRST node with d == d1.
+bool find_join_and_leaving(mcf_ns *s)
+{
+    const int in_arc = s->in_arc;
+    const bool lower = s->state[in_arc] == MCF_STATE_LOWER;
+    const int tail = s->tail[in_arc], head = s->head[in_arc];
+    // side A climbs from the tail, side B from the head; the FIRST path starts at the tail when the arc is at its lower bound
+    int a = tail, b = head;
+    const int32_t *const par = s->par.data(), *const sub = s->sub.data(), *const parc = s->par_arc.data();
+    const int8_t *const pdir = s->par_dir.data();
+    const int64_t *const flow = s->flow.data(), *const upper = s->upper.data();
+    const int64_t cap_in = s->upper[in_arc];
+    // residual of the tree arc above u when flow is pushed along the cycle: on the first path arcs pointing DOWN gain flow, on the second arcs pointing UP
+    int64_t d_first = kMax, d_second = kMax;
+    int u_first = -1, u_second = -1;
+    const int8_t gain_a = lower ? kDown : kUp;            // the direction whose arcs GAIN flow (residual = upper - flow) on side A ...
+    const int8_t gain_b = lower ? kUp : kDown;            // ... and on side B
+    while (a != b) {
+        if (sub[a] < sub[b]) {
+            const int e = parc[a];
+            int64_t room = flow[e];
+            if (pdir[a] == gain_a) room = upper[e] >= kMax ? kInf : upper[e] - room;
+            if (lower) { if (room < d_first) { d_first = room; u_first = a; } }
+            else { if (room <= d_second) { d_second = room; u_second = a; } }
+            a = par[a];
+        } else {
+            const int e = parc[b];
+            int64_t room = flow[e];
+            if (pdir[b] == gain_b) room = upper[e] >= kMax ? kInf : upper[e] - room;
+            if (lower) { if (room <= d_second) { d_second = room; u_second = b; } }
+            else { if (room < d_first) { d_first = room; u_first = b; } }
+            b = par[b];
+        }
+    }
+    s->join = a;
+    const int first = lower ? tail : head, second = lower ? head : tail;
+    // NS.cs:952: delta starts at the entering arc's capacity; the first path replaces it only with something strictly smaller, the second
+    // with anything not larger
+    int64_t delta = cap_in;
+    int side = 0;
+    if (u_first >= 0 && d_first < delta) { delta = d_first; s->u_out = u_first; side = 1; }
+    if (u_second >= 0 && d_second <= delta) { delta = d_second; s->u_out = u_second; side = 2; }
+    s->delta = delta;
+    if (side == 1) { s->u_in = first; s->v_in = second; }
+    else { s->u_in = second; s->v_in = first; }
+    s->out_on_tail_path = side != 0 && ((side == 1) == (first == tail));
+    return side != 0;
+}
+
 // One pivot with a given entering arc, in two halves.  pivot_front does what the next search depends on -- the cycle, the State[] writes and
 // the potentials of the subtree that is about to move (handed to the engine as they arise) -- and returns true when the problem is
 // found unbounded (NS.cs:321-325).  pivot_back does the rest (flows around the cycle, re-hanging the subtree): the solve loop runs it
@@ -649,8 +710,7 @@ bool pivot_front(mcf_ns *s, int arc, double *t_pot)
     s->moved_n = 0;
     s->moved_sent = 0;
     s->sigma = 0;
-    find_join(s);
-    const bool change = s->change = find_leaving(s);
+    const bool change = s->change = s->fused_cycle_search ? find_join_and_leaving(s) : (find_join(s), find_leaving(s));
     if (!change && s->delta == 0) return true;
     decide_states(s, change);
     // the engine hears about the state writes before any piece of the potential list (the pieces may start travelling at once)
@@ -1078,6 +1138,7 @@ int mcf_ns_prepare(mcf_ns *s)
         s->renumber_every = 128.0;
         if (const char *u = getenv("MCF_NS_RENUMBER")) { const double v = atof(u); if (v > 0) { s->renumber_every = v; s->renumber_forced = true; } }
         s->seq_walk = !(getenv("MCF_NS_SEQWALK") && getenv("MCF_NS_SEQWALK")[0] == '0');
+        s->fused_cycle_search = !(getenv("MCF_NS_FUSED_CYCLE") && getenv("MCF_NS_FUSED_CYCLE")[0] == '0');
     }
     s->cands.assign((size_t)std::max(1, s->world), mcf_candidate{0, 0xFFFFFFFFu, -1, 0, 0xFFFFFFFFu, -1});
     if (s->shard_mode == mcf_ns::kHost) { rc = mcf_exchange_open(&s->exchange, s->exchange_name.c_str(), s->rank, s->world); if (rc) return rc; }

@@ -519,6 +519,16 @@ class HostExchange:
         self.close()
 
 
+def _bench_update(self, count, reps=20):
+    """mcf_engine_bench_update: (avg ns, min ns, algorithmic bytes) of the potential-update kernel over `count` distinct nodes."""
+    avg, mn, nb = C.c_double(), C.c_double(), C.c_int64()
+    L.check(L.lib().mcf_engine_bench_update(self._h, count, reps, C.byref(avg), C.byref(mn), C.byref(nb)))
+    return avg.value, mn.value, nb.value
+
+
+PivotEngine.bench_update = _bench_update
+
+
 def _bench_search(self, reps=1000):
     avg, mn = C.c_double(), C.c_double()
     L.check(L.lib().mcf_engine_bench_search(self._h, reps, C.byref(avg), C.byref(mn)))
