@@ -309,6 +309,7 @@ typedef struct mcf_engine_stats {
     int64_t rc_recomputes;        /* RC layout: potential lists naming more than a sixteenth of the nodes, after which every reduced cost of the
                                      shard was computed again instead of shifting the listed nodes' arcs one by one */
     int64_t renumberings;         /* mcf_engine_renumber_nodes calls */
+    int64_t heap_compactions;     /* candidate cache: times the heap of touched arcs was swept of its outdated entries */
     int64_t rc_reloads_in_grid;   /* mcf_engine_reload_potentials carried out by the resident RC grid itself (the workgroups copy the bound array,
                                      meet at a grid-wide barrier and compute their arcs' reduced costs again) instead of stopping the grid */
     int64_t shift_grid;           /* 1: the candidate cache's grid is the one that is patched straight from the request (register-resident arcs

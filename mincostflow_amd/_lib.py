@@ -54,7 +54,7 @@ class EngineStats(C.Structure):
                 ("bytes_per_scan", C.c_int64), ("resident", C.c_int64), ("resident_launches", C.c_int64),
                 ("resident_requests", C.c_int64), ("resident_scan_ns", C.c_double), ("resident_kernel_ns", C.c_double), ("candidates", C.c_int64),
                 ("host_decided", C.c_int64), ("arcs_checked", C.c_int64), ("initial_block_size", C.c_int32), ("current_block_size", C.c_int32),
-                ("comm_ranks", C.c_int32), ("reserved", C.c_int32), ("async_refreshes", C.c_int64), ("scan_bytes_read", C.c_int64), ("rc_layout", C.c_int64), ("rc_recomputes", C.c_int64), ("renumberings", C.c_int64), ("rc_reloads_in_grid", C.c_int64), ("shift_grid", C.c_int64), ("shift_lists", C.c_int64), ("mirror_uploads", C.c_int64),
+                ("comm_ranks", C.c_int32), ("reserved", C.c_int32), ("async_refreshes", C.c_int64), ("scan_bytes_read", C.c_int64), ("rc_layout", C.c_int64), ("rc_recomputes", C.c_int64), ("renumberings", C.c_int64), ("heap_compactions", C.c_int64), ("rc_reloads_in_grid", C.c_int64), ("shift_grid", C.c_int64), ("shift_lists", C.c_int64), ("mirror_uploads", C.c_int64),
                 ("phase_shift_ns", C.c_double), ("phase_values_ns", C.c_double), ("phase_scan_ns", C.c_double)]
 
     def as_dict(self):

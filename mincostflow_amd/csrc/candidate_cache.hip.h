@@ -122,12 +122,13 @@ void cand_absorb_pivot(mcf_engine *e)
     e->pivot_arcs.clear();
     e->pivot_degree = 0;
     e->pivot_overflow = false;
-    if (e->heap.size() > (1u << 18)) {          // drop what lazy deletion left behind
+    if (e->heap.size() > e->heap_compact_above) {          // drop what lazy deletion left behind
         size_t keep = 0;
         for (size_t i = 0; i < e->heap.size(); ++i)
             if (e->heap[i].stamp == e->arc_stamp[e->heap[i].p]) e->heap[keep++] = e->heap[i];
         e->heap.resize(keep);
         std::make_heap(e->heap.begin(), e->heap.end(), CandHeapAfter());
+        e->st.heap_compactions += 1;
     }
 }
 

@@ -233,6 +233,7 @@ struct mcf_engine {
     uint32_t async_at = 0, posted_at = 0;
     int patch_capacity = 0;                       // potential patches one request / one staged update can carry (2 * node_count + 256)
     int cand_max_nodes = 256, cand_refresh_low = 12;      // sweep on config 3 (profiles/r03_cand_nodes_sweep.txt): 192-384 nodes evaluated on the host beat a device round trip
+    size_t heap_compact_above = 1u << 18;         // heap entries above which the stale ones are swept out (MCF_HIP_CAND_HEAP_COMPACT: tests)
     // where the host's time goes in candidate mode (TSC ticks; printed by mcf_engine_destroy when MCF_HIP_CAND_DEBUG is set)
     double tk_absorb = 0, tk_decide = 0, tk_post = 0, tk_collect = 0, tk_probe = 0;
     int64_t n_sync_posts = 0, n_async_waits = 0, n_gap_pivots = 0, n_heap_push = 0, n_heap_pop = 0, n_list_skip = 0;
@@ -1212,6 +1213,7 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
         if (const char *u = getenv("MCF_HIP_CAND_EPOCH0")) { const unsigned long long v = strtoull(u, nullptr, 10); if (v >= 1 && v <= 0xFFFFFFFFull) e->cand_now = (uint32_t)v; }    // tests: start close to the wrap
         if (const char *u = getenv("MCF_HIP_CAND_NODES")) { const int v = atoi(u); if (v >= 0 && v <= 4096) e->cand_max_nodes = v; }
         if (const char *u = getenv("MCF_HIP_CAND_REFRESH")) { const int v = atoi(u); if (v >= 0 && v <= 4096) e->cand_refresh_low = v; }
+        if (const char *u = getenv("MCF_HIP_CAND_HEAP_COMPACT")) { const long long v = atoll(u); if (v >= 1 && v <= (1ll << 30)) e->heap_compact_above = (size_t)v; }
     }
     // the pending lists grow to a subtree's size: get (and touch) their memory now, not in the middle of a solve
     e->pend_node.assign((size_t)e->patch_capacity, 0); e->pend_val.assign((size_t)e->patch_capacity, 0);

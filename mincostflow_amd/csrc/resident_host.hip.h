@@ -62,6 +62,12 @@ constexpr int kBucketNodes = 131072;        // 1 MB of int64 potentials per rang
 constexpr int kBucketMinArcs = 2 << 20;
 constexpr int kResidentMaxGrid = 256;       // one workgroup (64..1024 threads) per CU: always co-resident, every CU gathers
 constexpr uint32_t kResidentIdleTicks = 25000000u;   // 0.25 s of s_memrealtime
+uint32_t resident_idle_ticks()                       // MCF_HIP_IDLE_MS: tests shorten it so that grids leave between two searches
+{
+    uint32_t x = kResidentIdleTicks;
+    if (const char *u = getenv("MCF_HIP_IDLE_MS")) { const long long ms = atoll(u); if (ms >= 1 && ms <= 10000) x = (uint32_t)(ms * 100000); }
+    return x;
+}
 
 template <typename T, int RULE, bool OPT>
 void launch_resident_r(mcf_engine *e, const ResidentParams<T> &p)
@@ -117,7 +123,7 @@ int launch_resident_rc(mcf_engine *e, uint32_t start_seq)
     p.state = e->d_state; p.rc = e->d_rc; p.pi = e->d_pi; p.adj_start = e->d_adj_start; p.adj = e->d_adj; p.slots = e->d_slots;
     p.mailbox = e->mailbox; p.exit_word = e->d_exit;
     p.base = e->begin; p.count_padded = e->count_padded; p.m_s = e->d.search_arc_num; p.window = e->rc_window;
-    p.start_seq = start_seq; p.idle_ticks = kResidentIdleTicks; p.narrow = e->d.int_width == 32 ? 1 : 0;
+    p.start_seq = start_seq; p.idle_ticks = resident_idle_ticks(); p.narrow = e->d.int_width == 32 ? 1 : 0;
     p.max_pi = e->patch_capacity; p.max_st = e->mailbox_max_st; p.poll_replicas = e->poll_replicas; p.poll_sleep = e->poll_sleep;
     p.src = e->d_src; p.tgt = e->d_tgt; p.cost = e->d_cost; p.n_nodes = e->d.node_count;
     p.host_pi = e->d_ext_pi; p.barrier = e->d_barrier;
@@ -140,7 +146,7 @@ int launch_resident(mcf_engine *e, uint32_t start_seq)
     p.src = e->d_src; p.tgt = e->d_tgt; p.cost = (const T *)e->d_cost; p.state = e->d_state; p.pi = (T *)e->d_pi;
     p.slots = e->d_slots; p.orig = e->bucket_nodes > 0 ? e->d_orig : nullptr; p.mailbox = e->mailbox; p.exit_word = e->d_exit;
     p.base = e->begin; p.count_padded = e->count_padded; p.m_s = e->d.search_arc_num;
-    p.start_seq = start_seq; p.idle_ticks = kResidentIdleTicks; p.n_nodes = e->d.node_count; p.max_pi = e->patch_capacity; p.max_st = e->mailbox_max_st; p.poll_replicas = e->poll_replicas; p.poll_sleep = e->poll_sleep;
+    p.start_seq = start_seq; p.idle_ticks = resident_idle_ticks(); p.n_nodes = e->d.node_count; p.max_pi = e->patch_capacity; p.max_st = e->mailbox_max_st; p.poll_replicas = e->poll_replicas; p.poll_sleep = e->poll_sleep;
     const bool opt = e->d.semantics == MCF_SEM_OPTIMIZED;
     switch (e->d.rule) {
     case MCF_RULE_BEST_ELIGIBLE: launch_resident_r<T, MCF_RULE_BEST_ELIGIBLE, false>(e, p); break;

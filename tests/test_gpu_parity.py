@@ -1246,3 +1246,50 @@ def test_raw_engine_follows_a_relabelling_of_its_nodes(mode, bound, monkeypatch)
         assert eng.stats()["renumberings"] == 4
     with pytest.raises(M.McfError):
         eng.renumber_nodes(np.zeros(n, np.int32))          # not a permutation
+
+
+@pytest.mark.gpu
+def test_candidate_heap_is_swept_of_outdated_entries(monkeypatch):
+    """candidate_cache.hip.h: the heap of touched arcs deletes lazily and is compacted when it outgrows a bound (2^18 entries; config 5 reaches it).
+    With the bound at 64 entries a mid-size solve compacts hundreds of times -- and still takes the oracle's pivots."""
+    monkeypatch.setenv("MCF_HIP_CAND_HEAP_COMPACT", "64")
+    g = M.netgen_like(13502460, 20_000, 70_000, 140, 140)
+    p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
+    o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, O.RULE_BEST, flags=0)
+    assert st == st_o == O.OPTIMAL and np.array_equal(ns.trace(), tr_o)
+    e = ns.get_metrics()["engine"]
+    assert e["candidates"] == 1 and e["heap_compactions"] > 20, e["heap_compactions"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+def test_grid_that_left_on_its_idle_timeout_comes_back(mode, monkeypatch):
+    """A resident grid that hears nothing for its idle time leaves by itself; the next search finds the exit record while it waits for its
+    answer and starts the grid again (collect / cand_collect -> resident_restart).  With the idle time cut to 5 ms and pauses between the
+    searches that happens before every other search -- with patches queued meanwhile, in every engine mode (the grid that is patched straight
+    from the request gets its arrays written again from the host's mirrors and the waiting request put there again without patches)."""
+    import time
+    flags = _mode_flags(mode, monkeypatch)
+    monkeypatch.setenv("MCF_HIP_IDLE_MS", "5")
+    rng = np.random.default_rng(77)
+    for m_s, n in [(60001, 17000), (9001, 1200)]:
+        a = _random_soa(rng, m_s, n, 60, 500, extra=0)
+        eng = M.PivotEngine(n, m_s, m_s, rule=M.PivotRule.BestEligible, flags=flags)
+        eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+        for it in range(10):
+            f, e, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+            assert eng.find_entering() == (f, e, c), (m_s, it)
+            if f:
+                a["state"][e] = 0
+                eng.patch_state([e], [0])
+            nodes = rng.choice(n, size=int(rng.choice([1, 4, 300, 2000])), replace=False).astype(np.int32)
+            sigma = int(rng.integers(-30, 31))
+            a["pi"][nodes] += sigma
+            eng.update_potential(nodes, sigma)
+            if it % 2 == 0:
+                time.sleep(0.03)          # the grid is gone when the next search is posted
+        st = eng.stats()
+        if st["resident"]:
+            assert st["resident_launches"] >= 4, st["resident_launches"]
+        assert np.array_equal(eng.download_pi(), a["pi"]) and np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
+        assert eng.check_reduced_costs() == (0, -1)
