@@ -417,7 +417,10 @@ typedef struct mcf_ns_metrics {
     double setup_us;              /* mcf_ns_prepare: standard form, start basis, engine creation, upload */
     double loop_us;               /* the pivot loop alone (inputs already resident in HBM) */
     int32_t search_arc_num, block_size, int_width, reserved;
-    int64_t degenerate_pivots, potential_nodes;
+    int64_t degenerate_pivots;
+    int64_t potential_nodes;      /* nodes whose potential the host walked over: the moved subtree's, or -- inside mcf_ns_solve with 64-bit engines --
+                                     the REST of the tree's when that is the smaller side (reduced costs only see differences, so moving
+                                     everything else by -sigma is the same search; the common offset is taken out before Solve() returns) */
     mcf_engine_stats engine;
     /* the remaining SolverMetrics fields (OptimizationTypes.cs:53-59), filled like NS.cs:262-270, :344-357 */
     int32_t initial_block_size, final_block_size;      /* Block Search, plain flavour; 0 otherwise (NS.cs:263-270, :348-355) */

@@ -202,13 +202,16 @@ struct mcf_engine {
     mcf::hvec<AdjEnt> adj;                      // arcs incident to each node, with what a re-evaluation needs next to each other
     // every change carries the number of the search it precedes ("epoch"); a snapshot taken at epoch P knows all changes stamped <= P
     mcf::hvec<uint32_t> node_at, arc_at;        // epoch of the node's last potential change / the arc's last state change
-    mcf::hvec<uint32_t> arc_stamp;              // version of the arc's key; heap entries of an older version are stale
     mcf::hvec<int32_t> adj_pos;                 // where the two entries of an arc sit in adj (the second is -1 for a self loop): a state write reaches both
     uint32_t cand_now = 1;                        // epoch of the changes that are arriving
     uint32_t snap_at = 0;                         // epoch the candidate list reflects
     uint32_t heap_gap = 0;                        // latest epoch whose changes were NOT evaluated into the heap (a subtree too big to evaluate here)
     struct CandKey { int64_t c; uint32_t p; };
-    struct HeapEnt { int64_t c; uint32_t p; uint32_t stamp; uint32_t at; };      // at: the epoch of the touch that pushed it (= the arc's last touch while the entry is current)
+    // c, p: the key; at: the epoch of the touch that pushed it; u, v: the arc's end points.  An entry is CURRENT while nothing of its arc was
+    // touched after `at` (arc_at[p], node_at[u], node_at[v] all <= at): a later touch either pushed a newer entry or was a skipped one, i.e. a
+    // gap -- and no list older than a gap is ever judged against the heap (cand_decide).  (Rounds 1-2 kept a version counter per arc and
+    // bumped it for every arc an evaluation looked at: 80 scattered read-modify-writes per pivot on the headline workload.)
+    struct HeapEnt { int64_t c; uint32_t p; uint32_t at; int32_t u, v; };
     std::vector<HeapEnt> heap;                    // min-heap of the current keys of the arcs touched since (lazy deletion through arc_stamp)
     std::vector<int32_t> pivot_nodes, pivot_arcs; // touched since the last search: evaluated when the next search begins (all values final by then)
     int64_t pivot_degree = 0;
@@ -228,6 +231,12 @@ struct mcf_engine {
     std::vector<CandKey> cand_list;               // sorted; complete below cand_thr as of snap_at
     std::vector<int32_t> cand_ends;               // the end points of the listed arcs (2 per entry), looked up once when the list is installed
     size_t cand_ptr = 0;
+    // what cand_decide found valid last time: the heap's top entry (tp_*) and the list's first clean entry (hd_*), remembered with their arc
+    // and end points so that a touch of any of them (cand_note_node / cand_note_arc) can revoke it
+    bool tp_ok = false, hd_ok = false;
+    int32_t tp_a = -1, tp_u = -1, tp_v = -1, hd_a = -1, hd_u = -1, hd_v = -1;
+    uint32_t tp_at = 0;
+    size_t hd_ptr = 0;
     CandKey cand_thr{0, 0xFFFFFFFFu};             // p == kNone: the list holds every eligible arc
     bool async_posted = false;                    // a refresh is on its way while the host keeps answering from the current list
     uint32_t async_at = 0, posted_at = 0;
@@ -1201,7 +1210,6 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
         cand_build_adjacency(e);
         e->node_at.assign(n, 0u);
         e->arc_at.assign(m_s, 0u);
-        e->arc_stamp.assign(m_s, 0u);
         e->cand_now = 1;
         e->snap_at = 0;
         e->heap_gap = 0;
@@ -1590,6 +1598,8 @@ int mcf_engine_renumber_nodes(mcf_engine *e, const int32_t *new_of)
         for (int u = 0; u < n; ++u) at[new_of[u]] = e->node_at[u];
         std::copy(at.begin(), at.end(), e->node_at.begin());
         for (size_t i = 0; i < e->cand_ends.size(); ++i) e->cand_ends[i] = new_of[e->cand_ends[i]];
+        for (auto &h : e->heap) { h.u = new_of[h.u]; h.v = new_of[h.v]; }
+        e->tp_ok = e->hd_ok = false;
         for (int32_t &u : e->pivot_nodes) u = new_of[u];
         for (int32_t &u : e->sync_nodes) u = new_of[u];
         for (auto &x : e->rc_sync) x.node = new_of[x.node];

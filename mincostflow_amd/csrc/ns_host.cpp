@@ -423,6 +423,9 @@ void shift_potentials(mcf_ns *s)
     s->sigma = s->pi[s->v_in] - s->pi[s->u_in] - dir_in * s->cost[s->in_arc];
     int count = s->sub[s->u_out];
     int first = s->u_out, last = s->fin[s->u_out];
+    // (the common offset pi[root] that this builds up is bounded: past 2^60 the complement is never walked again, so it stops growing and every
+    // potential stays representable -- the reference's values differ from ours by exactly that offset until normalise_potentials takes it out)
+    if (s->shift_smaller_side && (s->pi[s->root] > (1ll << 60) || s->pi[s->root] < -(1ll << 60))) s->shift_smaller_side = false;
     if (s->shift_smaller_side && 2 * (int64_t)count > (int64_t)s->n + 1) {
         // Reduced costs only see differences of potentials: moving the subtree by sigma and moving EVERYTHING ELSE by -sigma give the same
         // search results.  Inside mcf_ns_solve the smaller side is walked -- the rest of the preorder list, from the node after the
@@ -1248,6 +1251,11 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
     s->hand_over = false;
     s->shift_smaller_side = false;
     if (!rc) rc = normalise_potentials(s);
+    else {
+        // after an engine error the engines are not told any more, but the caller's view of _pi is the reference's: pi[root] = 0
+        const int64_t off = s->pi[s->root];
+        if (off != 0) for (int u = 0; u <= s->n; ++u) s->pi[u] -= off;
+    }
     s->reload_min = 0;
     restore_node_ids(s);             // the caller's node ids again (the parked engines keep the relabelled ones: Solve() is single-shot)
     const char *first_error = rc ? mcf_last_error() : nullptr;
