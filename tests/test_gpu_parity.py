@@ -1200,7 +1200,9 @@ def test_solve_with_nodes_relabelled_in_thread_order(mode, monkeypatch):
             assert np.array_equal(ns.trace(), tr_o), (name, sem, rule)
             assert ns.get_total_cost() == o.total_cost and np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
             m = ns.get_metrics()
-            assert m["engine"]["renumberings"] >= 5, (name, sem, rule, m["engine"]["renumberings"])
+            # (an engine that shares its device with other solvers' grids declines: a relabelling stops and restarts the resident grid)
+            shared = not rc_layout and bool(flags & M.ENGINE_SHARE_DEVICE)
+            assert (m["engine"]["renumberings"] == 0) if shared else (m["engine"]["renumberings"] >= 5), (name, sem, rule, m["engine"]["renumberings"])
             v = ns.validate()
             assert v["valid"] == 1 and v["objective"] == v["dual_cost"] == o.total_cost
 
