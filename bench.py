@@ -92,7 +92,7 @@ def cpu_baseline(g, rule, budget_s, reference_default=False, vector_width=VECTOR
     vector_width: Vector<long>.Count of the machine whose optimized Block Search is reproduced (4 = x64: a boundary hit in the "SIMD" part
     scans on to the end of the range; 0 = not hardware accelerated: stop at the block boundary).  Only that rule reads it."""
     from oracle import ns_oracle as O
-    core = pin_to_one_core()
+    core, affinity_before = pin_to_one_core()
     p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
     if reference_default:
         o = O.Oracle(p, O.SEM_CSHARP, {0: O.RULE_FIRST, 1: O.RULE_BEST, 2: O.RULE_BLOCK}[rule], auto_config=True)
@@ -107,6 +107,7 @@ def cpu_baseline(g, rule, budget_s, reference_default=False, vector_width=VECTOR
         done += k
         chunk = min(chunk * 2, 1 << 16)
     dt = time.perf_counter() - t0
+    restore_affinity(affinity_before)
     ph = o.phase_us()
     sample = (f"whole solve ({done} pivots)" if ended else f"first {done} pivots of the same solve") + f", {dt:.1f} s of CPU work"
     return {"value": done / dt, "unit": "pivots/s", "cores": 1, "kind": "port", "sample": sample,
@@ -118,20 +119,26 @@ def cpu_baseline(g, rule, budget_s, reference_default=False, vector_width=VECTOR
             "not_timed": "LEMON (needs its CMake-generated config.h: unbuildable here) and the C# reference (no .NET toolchain in the image)"}
 
 
-_PINNED = None
-
-
 def pin_to_one_core():
-    """The CPU legs run on ONE core (the reference is single-threaded): the core this thread is on when the first of them starts.  Returns its number."""
-    global _PINNED
-    if _PINNED is None:
-        try:
-            here = os.sched_getcpu()
-            os.sched_setaffinity(0, {here})
-            _PINNED = here
-        except (AttributeError, OSError):
-            _PINNED = -1
-    return _PINNED
+    """The CPU legs run on ONE core (the reference is single-threaded): the core this thread is on when the leg starts.
+    Returns (core, the affinity to give back to restore_affinity when the leg is over)."""
+    before = os.sched_getaffinity(0)
+    try:
+        import ctypes
+        here = ctypes.CDLL(None).sched_getcpu()
+        if here < 0 or here not in before:
+            here = min(before)
+        os.sched_setaffinity(0, {here})
+        return here, before
+    except (AttributeError, OSError):
+        return -1, before
+
+
+def restore_affinity(before):
+    try:
+        os.sched_setaffinity(0, before)
+    except OSError:
+        pass
 
 
 def other_config(M, name, local_rank, cpu_seconds):

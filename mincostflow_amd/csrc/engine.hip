@@ -2011,7 +2011,12 @@ int mcf_engine_comm_init(mcf_engine *e, const uint8_t id[128], int32_t rank, int
     e->st.comm_ranks = world;
     if (r->comm_count) { int seen = 0; if (r->comm_count(e->comm, &seen) == 0) e->st.comm_ranks = seen; }     // as the communicator itself reports it
     {
-        HIP_TRY(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+        // The collective must not share a hardware queue with a resident grid (a queue runs its packets in order: the all-gather would
+        // wait until the grid leaves).  HIP multiplexes the streams of one priority over a handful of queues (GPU_MAX_HW_QUEUES, 4), so
+        // with a few engines alive two of their streams do share one; streams of another priority have queues of their own.
+        int prio_least = 0, prio_greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&e->comm_stream, hipStreamNonBlocking, prio_greatest));
         HIP_TRY(hipHostMalloc((void **)&e->x_send, sizeof(mcf_engine::XRec), hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(hipHostMalloc((void **)&e->x_recv, sizeof(mcf_engine::XRec) * world, hipHostMallocMapped | hipHostMallocCoherent));
         memset(e->x_send, 0, sizeof(mcf_engine::XRec));

@@ -1089,7 +1089,9 @@ int mcf_ns_prepare(mcf_ns *s)
         if (s->shard_mode == mcf_ns::kRccl && dr.resident_workgroups == 0) {
             // the collective's kernel needs room beside the resident grid: leave one CU per XCD alone (mcf_engine_comm_init checks)
             const int cus = mcf_device_compute_units(dr.device);
-            if (cus >= 64) dr.resident_workgroups = cus - 8;
+            int leave = 8;
+            if (const char *u = getenv("MCF_NS_RCCL_FREE_CUS")) { const int v = atoi(u); if (v >= 0 && v < cus) leave = v; }
+            if (cus >= 64) dr.resident_workgroups = cus - leave;
         }
         if (s->shard_mode == mcf_ns::kGroup) {
             dr.device = s->group_devices[r];

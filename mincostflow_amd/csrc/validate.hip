@@ -138,6 +138,8 @@ __device__ __forceinline__ I64x4 load4(const int64_t *p, int i0, int m)
     return r;
 }
 
+// SKIP (measurement only, MCF_VAL_SKIP; results are wrong with it): 1 = no scatter, 2 = no potential gathers
+template <int SKIP>
 __global__ __launch_bounds__(kValThreads) void validate_arcs(const int32_t *__restrict__ src, const int32_t *__restrict__ tgt,
                                                              const int64_t *__restrict__ lower, const int64_t *__restrict__ upper,
                                                              const int64_t *__restrict__ cost, const int64_t *__restrict__ flow,
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(kValThreads) void validate_arcs(const int32_t *__re
 #pragma unroll
         for (int u = 0; u < kValTiles; ++u)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { ps[u][j] = pi[s[u].v[j]]; pt[u][j] = pi[t[u].v[j]]; }
+            for (int j = 0; j < 4; ++j) { ps[u][j] = (SKIP & 2) ? (int64_t)s[u].v[j] : pi[s[u].v[j]]; pt[u][j] = (SKIP & 2) ? (int64_t)t[u].v[j] : pi[t[u].v[j]]; }
 #pragma unroll
         for (int u = 0; u < kValTiles; ++u) {
             const int i0 = base + u * step;
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(kValThreads) void validate_arcs(const int32_t *__re
                 if (in && rc < 0) a.sum1 -= ((uint64_t)uj - (uint64_t)lj) * (0 - (uint64_t)rc);
                 run_flow += (uint64_t)fj;
                 run_low += (uint64_t)lj;
+                if (SKIP & 1) { a.sum1 += run_flow ^ run_low; continue; }
                 if (fj != 0) atomicAdd(net + t[u].v[j], (unsigned long long)(0 - (uint64_t)fj));
                 if (lj != 0) atomicAdd(adj + t[u].v[j], (unsigned long long)lj);
                 if (j == 3 || s[u].v[j + 1 < 4 ? j + 1 : 3] != s[u].v[j]) {
@@ -358,7 +361,9 @@ int mcf_validator_run(mcf_validator *v, int32_t supply_type, int64_t reported_co
     const int node_groups = std::max(1, std::min(max_groups, (v->n + kValThreads - 1) / kValThreads));
     HIP_TRY(hipEventRecord(v->ev0, v->stream));
     HIP_TRY(hipMemsetAsync(v->net, 0, 2 * ((size_t)v->n + 1) * 8, v->stream));
-    hipLaunchKernelGGL(validate_arcs, dim3(arc_groups), dim3(kValThreads), 0, v->stream, v->src, v->tgt, v->lower, v->upper, v->cost, v->flow,
+    const int skip = getenv("MCF_VAL_SKIP") ? atoi(getenv("MCF_VAL_SKIP")) & 3 : 0;     // experiments only
+    auto arcs_kernel = skip == 0 ? validate_arcs<0> : (skip == 1 ? validate_arcs<1> : (skip == 2 ? validate_arcs<2> : validate_arcs<3>));
+    hipLaunchKernelGGL(arcs_kernel, dim3(arc_groups), dim3(kValThreads), 0, v->stream, v->src, v->tgt, v->lower, v->upper, v->cost, v->flow,
                        v->pi, v->net, v->adj, v->m, v->partials);
     hipLaunchKernelGGL(validate_nodes, dim3(node_groups), dim3(kValThreads), 0, v->stream, v->supply, v->pi, v->net, v->adj, v->n, supply_type,
                        v->partials + arc_groups);

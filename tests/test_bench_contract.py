@@ -31,14 +31,19 @@ def _check(line, with_cpu):
         assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
 
 
-@pytest.mark.parametrize("name", ["r01_bench_n1_final.json", "r02_bench_n1.json"])
+@pytest.mark.parametrize("name", ["r01_bench_n1_final.json", "r02_bench_n1.json", "r03_bench_n1.json"])
 def test_committed_bench_line_keeps_the_contract(name):
     line = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
     _check(line, with_cpu=True)
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1
-    if name.startswith("r02"):
+    if not name.startswith("r01"):
         assert line["roofline"]["traffic_source"] and line["cpu_baseline"]["host_cpu"] and set(line["other_configs"]) == {"config2", "config4"}
         assert line["engine"]["candidate_cache"] is True and line["every_search_on_the_device"]["identical_pivot_sequence"] is True
+    if name.startswith("r03"):
+        # which machine's optimized Block Search the legs reproduce, the CPU leg on one named core, the update kernels priced, int32 scan rows
+        assert "Vector<long>.Count = 4" in line["config"]["semantics"] and line["cpu_baseline"]["pinned_to_cpu"] >= 0 and line["potential_update_microbench"]
+        assert any(r.get("dtype") == "i32" for r in line["scan_microbench"])
+        assert line["sharded"]["identical_pivot_sequence"] is True and line["sharded"]["variants"]["rccl_all_gather"]["us_per_pivot"] < 100
 
 
 @pytest.mark.gpu
