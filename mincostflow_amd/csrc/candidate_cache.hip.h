@@ -64,7 +64,14 @@ inline int cand_note_nodes_blind(mcf_engine *e, int32_t count, const int32_t *no
         if (e->blind_sets > 1 && e->stream_lines > 0) { const int rc = resident_stop(e); if (rc) return rc; }
     }
     e->pend_node.insert(e->pend_node.end(), nodes, nodes + count);
-    e->pend_val.insert(e->pend_val.end(), values, values + count);
+    if (values) e->pend_val.insert(e->pend_val.end(), values, values + count);
+    else {
+        // the bound array holds them; the shift grid never reads a big list's values (cand_post_shift sends the shift, or takes the values
+        // of that moment from the array itself)
+        const size_t at = e->pend_val.size();
+        e->pend_val.resize(at + (size_t)count);
+        if (!e->shift_grid) for (int i = 0; i < count; ++i) e->pend_val[at + i] = e->ext_pi[nodes[i]];
+    }
     e->blind_count = e->pend_node.size();
     // a list refresh that has arrived meanwhile is taken in now, so that this list can start travelling
     if (e->async_posted && cand_records_ready(e, 0)) { const int rc = cand_collect(e, e->async_at); if (rc) return rc; }

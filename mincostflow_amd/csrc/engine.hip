@@ -1315,17 +1315,38 @@ int mcf_engine_update_potential(mcf_engine *e, int32_t count, const int32_t *nod
     return MCF_OK;
 }
 
-int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values)
+}  // extern "C"
+
+namespace {
+
+// the nodes of a list are inside the graph (and, for 32-bit engines, their values inside int32); values == nullptr: the bound array holds them
+int check_potential_list(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values)
 {
-    if (!e || count < 0 || (count && (!nodes || !values))) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_set_potential: bad arguments");
+    const uint32_t n = (uint32_t)e->d.node_count;
+    uint32_t beyond = 0;
+    for (int i = 0; i < count; ++i) beyond |= (uint32_t)((uint32_t)nodes[i] >= n);      // no early exit: the loop vectorises
+    if (beyond) for (int i = 0; i < count; ++i) if ((uint32_t)nodes[i] >= n) return mcf::fail(MCF_ERR_INVALID, "node %d out of range", nodes[i]);
+    if (e->d.int_width == 32)
+        for (int i = 0; i < count; ++i)
+            if (!fits32(values ? values[i] : e->ext_pi[nodes[i]])) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d leaves int32; create the engine with int_width 64", nodes[i]);
+    return MCF_OK;
+}
+
+// appends `count` values to pend_val: the caller's, or the bound array's
+void pend_values_append(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values)
+{
+    if (values) { e->pend_val.insert(e->pend_val.end(), values, values + count); return; }
+    const size_t at = e->pend_val.size();
+    e->pend_val.resize(at + (size_t)count);
+    for (int i = 0; i < count; ++i) e->pend_val[at + i] = e->ext_pi[nodes[i]];
+}
+
+int set_potential_impl(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values)
+{
     if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
     if (count == 0) return MCF_OK;
     if (count > e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "%d nodes in a graph of %d", count, e->d.node_count);
-    const bool narrow = e->d.int_width == 32;
-    for (int i = 0; i < count; ++i) {
-        if ((unsigned)nodes[i] >= (unsigned)e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "node %d out of range", nodes[i]);
-        if (narrow && !fits32(values[i])) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d leaves int32; create the engine with int_width 64", nodes[i]);
-    }
+    if (const int rcc = check_potential_list(e, count, nodes, values)) return rcc;
     if (e->cand_on) {                 // the mirror stays authoritative in candidate mode
         if (!e->ext_pi) for (int i = 0; i < count; ++i) e->pi[nodes[i]] = values[i];      // bound potentials: the caller's array already holds them
         if (count > e->cand_max_nodes || e->pivot_overflow) {
@@ -1342,7 +1363,8 @@ int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes,
     }
     if (!e->pend_node.empty()) { int rc = resident_stop(e); if (!rc) rc = flush_pending(e); if (rc) return rc; }
     e->pend_node.assign(nodes, nodes + count);
-    e->pend_val.assign(values, values + count);
+    e->pend_val.clear();
+    pend_values_append(e, count, nodes, values);
     e->pend_shift = false;
     e->mirror_valid = false;
     e->st.potential_nodes += count;
@@ -1350,31 +1372,42 @@ int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes,
     return MCF_OK;
 }
 
-int mcf_engine_append_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values)
+int append_potential_impl(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values)
 {
-    if (!e || count < 0 || (count && (!nodes || !values))) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_append_potential: bad arguments");
     if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
     if (count == 0) return MCF_OK;
     if (e->cand_on) {              // candidate mode takes any number of calls; a piece that continues this pivot's list repeats none of its nodes
         e->cand_appending = e->pivot_overflow && e->blind_count > 0 && e->blind_epoch == e->cand_now;
-        const int rc = mcf_engine_set_potential(e, count, nodes, values);
+        const int rc = set_potential_impl(e, count, nodes, values);
         e->cand_appending = false;
         return rc;
     }
-    if (e->pend_node.empty()) return mcf_engine_set_potential(e, count, nodes, values);     // nothing queued yet
+    if (e->pend_node.empty()) return set_potential_impl(e, count, nodes, values);     // nothing queued yet
     if ((int64_t)e->pend_node.size() + count > e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "more nodes appended than the graph has: the lists of one pivot must not repeat nodes");
-    const bool narrow = e->d.int_width == 32;
-    for (int i = 0; i < count; ++i) {
-        if ((unsigned)nodes[i] >= (unsigned)e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "node %d out of range", nodes[i]);
-        if (narrow && !fits32(values[i])) return mcf::fail(MCF_ERR_OVERFLOW, "potential of node %d leaves int32; create the engine with int_width 64", nodes[i]);
-    }
+    if (const int rcc = check_potential_list(e, count, nodes, values)) return rcc;
     e->pend_node.insert(e->pend_node.end(), nodes, nodes + count);
-    e->pend_val.insert(e->pend_val.end(), values, values + count);
+    pend_values_append(e, count, nodes, values);
     e->pend_shift = false;
     e->mirror_valid = false;
     e->st.potential_nodes += count;
     resident_stream(e);
     return MCF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values)
+{
+    if (!e || count < 0 || (count && (!nodes || !values))) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_set_potential: bad arguments");
+    return set_potential_impl(e, count, nodes, values);
+}
+
+int mcf_engine_append_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values)
+{
+    if (!e || count < 0 || (count && (!nodes || !values))) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_append_potential: bad arguments");
+    return append_potential_impl(e, count, nodes, values);
 }
 
 int mcf_engine_bind_potentials(mcf_engine *e, const int64_t *pi)
@@ -1436,12 +1469,13 @@ int mcf_engine_reload_potentials(mcf_engine *e, int32_t changed_nodes)
 
 int mcf_engine_shift_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values, int64_t sigma)
 {
-    if (!e) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_shift_potential: bad arguments");
+    if (!e || count < 0 || (count && !nodes)) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_shift_potential: bad arguments");
+    if (count && !values && !e->ext_pi) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_shift_potential: values may only be left out when the potentials are bound (mcf_engine_bind_potentials)");
     const bool first = e->pend_node.empty();
     const bool same = first || (e->pend_shift && e->pend_sigma == sigma);
     e->call_shift_known = true;
     e->call_shift = sigma;
-    const int rc = mcf_engine_append_potential(e, count, nodes, values);
+    const int rc = append_potential_impl(e, count, nodes, values);
     e->call_shift_known = false;
     if (rc) return rc;
     if (count > 0 && !e->cand_on) { e->pend_shift = same; e->pend_sigma = sigma; }

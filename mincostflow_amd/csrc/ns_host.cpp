@@ -89,6 +89,7 @@ struct mcf_ns {
         double walk[32] = {0}, wait[32] = {0}, rest[32] = {0};
     } dbg;
     int moved_sent = 0;               // how many of them the engine already has (handed over during the walk)
+    bool moved_without_values = false;// the walk wrote no moved_val (run walk: the engines read the bound _pi where they need a value)
     int engine_rc = 0;                // first error of an engine call made from inside a pivot
     double piece_ticks = 0;           // time inside the hand-over calls made during the walks (part of the potential-update bucket)
     bool hand_over = false;           // a device engine is attached: state writes and potential pieces go to it as they arise
@@ -416,6 +417,50 @@ int walk_piece()                   // a big walk hands its nodes to the engine i
 }
                                    // 1024 .. 8192 measure alike on config 3, no hand-over at all costs 0.9 us per pivot
 
+// ---- runs of consecutive ids (after a relabelling in thread order the successor of node a is a + 1 almost everywhere).  Inside a run the
+// next address does not depend on the loaded successor (the exit test is a predicted branch, not a data dependency), so the loads of
+// consecutive nodes overlap and the hardware prefetcher sees a linear stream; a jump costs one mispredicted branch and a miss: 23-25 ns on the
+// hosts measured, which is what such a walk costs -- 2 400 jumps in a walk of 40 000 nodes after some 30 000 pivots.  (Measured and dropped:
+// eight successors compared per AVX2 step, run by run or fused with the update -- 2x faster on runs of 100 nodes, 1.4-2x SLOWER on the runs of
+// 16 that the solves have: the scalar loop's one branch per node predicts better than a vector loop's exit.)
+// the nodes first .. (count of them, in thread order) move by sigma, run by run; nodes (optional) receives them; returns the number of runs
+// that ended in a jump.  `next` receives the node behind the last one visited.
+int64_t walk_runs(mcf_ns *s, int first, int count, int64_t sigma, int32_t *nodes, int *next)
+{
+    int64_t *const pi = s->pi.data();
+    const int32_t *const nxt = s->nxt.data();
+    int64_t jumps = 0;
+    int i = 0, a = first;
+    if (nodes) {
+        while (i < count) {
+            int nx;
+            do {
+                nodes[i] = a;
+                pi[a] += sigma;
+                nx = nxt[a];
+                ++i;
+                if (nx != a + 1) { ++jumps; break; }
+                ++a;
+            } while (i < count);
+            a = nx;
+        }
+    } else {
+        while (i < count) {
+            int nx;
+            do {
+                pi[a] += sigma;
+                nx = nxt[a];
+                ++i;
+                if (nx != a + 1) { ++jumps; break; }
+                ++a;
+            } while (i < count);
+            a = nx;
+        }
+    }
+    *next = a;
+    return jumps;
+}
+
 void shift_potentials(mcf_ns *s)
 {
     // runs BEFORE the re-hanging: the nodes that move are the subtree of u_out as it hangs now, and u_in's new parent direction is known
@@ -439,26 +484,15 @@ void shift_potentials(mcf_ns *s)
     const int64_t sigma = s->sigma;
     s->moved_n = count;
     s->moved_as_reload = false;
+    s->moved_without_values = false;
     if (s->reload_min > 0 && count >= s->reload_min) {
         // A walk this long is cheaper for the engines as "reload _pi" than as a list (mcf_engine_reload_potentials): nothing is written down,
         // the walk only moves the potentials.  The hints need the node kWalkAhead steps back: a ring of that many.
         int64_t *const pi = s->pi.data();
         const int32_t *const nxt = s->nxt.data();
         if (s->renumbers > 0 && s->seq_walk) {
-            int i = 0, a = first;
-            int64_t jumps = 0;
-            while (i < count) {
-                int nx;
-                do {
-                    pi[a] += sigma;
-                    nx = nxt[a];
-                    ++i;
-                    if (nx != a + 1) { ++jumps; break; }
-                    ++a;
-                } while (i < count);
-                a = nx;
-            }
-            s->jumps_since_renumber += jumps;
+            int behind = 0;
+            s->jumps_since_renumber += walk_runs(s, first, count, sigma, nullptr, &behind);
             s->moved_as_reload = true;
             s->moved_sent = count;
             if (s->dbg.on) s->dbg.reload_walks += 1;
@@ -501,25 +535,16 @@ void shift_potentials(mcf_ns *s)
         // After a relabelling in thread order the successor of node a is a + 1 almost everywhere: walk in RUNS.  Inside a run the next
         // address does not depend on the loaded successor (the exit test is a predicted branch, not a data dependency), so the loads of
         // consecutive nodes overlap and the hardware prefetcher sees a linear stream; a jump costs one unpredicted miss.
+        // The engines have _pi bound (mcf_engine_bind_potentials): the list goes without values.
         int i = 0, a = first;
         int64_t jumps = 0;
+        s->moved_without_values = true;
         while (i < count) {
             const int stop = s->hand_over && count - (s->moved_sent + piece) >= piece / 2 ? std::max(i, s->moved_sent + piece) : count;
-            while (i < stop) {
-                int nx;
-                do {
-                    nodes[i] = a;
-                    vals[i] = (pi[a] += sigma);
-                    nx = nxt[a];
-                    ++i;
-                    if (nx != a + 1) { ++jumps; break; }
-                    ++a;
-                } while (i < stop);
-                a = nx;
-            }
+            if (stop > i) { jumps += walk_runs(s, a, stop - i, sigma, nodes + i, &a); i = stop; }
             if (i < count) {
                 const double tp = ticks();
-                if (!s->engine_rc) s->engine_rc = engines_append_potential(s, i - s->moved_sent, nodes + s->moved_sent, vals + s->moved_sent);
+                if (!s->engine_rc) s->engine_rc = engines_append_potential(s, i - s->moved_sent, nodes + s->moved_sent, nullptr);
                 s->piece_ticks += ticks() - tp;
                 s->moved_sent = i;
             }
@@ -1229,7 +1254,7 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         rc = s->engine_rc;
         if (!rc && s->moved_as_reload) rc = engines_reload_potentials(s, (int32_t)s->moved_n);
         else if (!rc && s->moved_n > s->moved_sent)
-            rc = engines_append_potential(s, (int32_t)(s->moved_n - s->moved_sent), s->moved.data() + s->moved_sent, s->moved_val.data() + s->moved_sent);
+            rc = engines_append_potential(s, (int32_t)(s->moved_n - s->moved_sent), s->moved.data() + s->moved_sent, s->moved_without_values ? nullptr : s->moved_val.data() + s->moved_sent);
         const double t2 = ticks();
         if (!rc) rc = engines_search_begin(s);
         const double t3 = ticks();

@@ -152,3 +152,39 @@ int mcf_block_adapt(const mcf_block_config *c, int32_t dynamic_min, int64_t arcs
 }
 
 }  // extern "C"
+
+// A SIGABRT (glibc's heap checks, a failed assertion inside a library underneath, std::terminate) leaves the C-level call stack in the file
+// that MCF_ABORT_TRACE_FILE names before the process dies -- test runners capture stderr, where the aborting party's own message goes.
+// Nothing is installed without that variable (tests/conftest.py sets it).
+#include <cstring>
+#include <execinfo.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <unistd.h>
+namespace {
+char g_trace_path[512];
+struct sigaction g_abort_before;      // e.g. Python's faulthandler: it gets the signal next
+void abort_trace(int sig)
+{
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    const int fd = open(g_trace_path, O_WRONLY | O_CREAT | O_APPEND, 0644);
+    if (fd >= 0) { backtrace_symbols_fd(frames, n, fd); (void)!write(fd, "----\n", 5); close(fd); }
+    backtrace_symbols_fd(frames, n, 2);
+    sigaction(sig, &g_abort_before, nullptr);
+    raise(sig);
+}
+__attribute__((constructor)) void install_abort_trace()
+{
+    const char *p = getenv("MCF_ABORT_TRACE_FILE");
+    if (!p || !p[0] || strlen(p) >= sizeof(g_trace_path)) return;
+    strcpy(g_trace_path, p);
+    void *warm[4];
+    (void)backtrace(warm, 4);             // loads libgcc now, not inside the handler
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = abort_trace;
+    sigemptyset(&sa.sa_mask);
+    sigaction(SIGABRT, &sa, &g_abort_before);
+}
+}  // namespace

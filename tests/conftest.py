@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# an abort underneath a test (glibc heap check, an assertion in a runtime library) leaves its C-level call stack here (util.cpp: abort_trace)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+os.environ.setdefault("MCF_ABORT_TRACE_FILE", os.path.join(ROOT, "gpurun_out", "abort_trace.txt"))
 
 
 def pytest_configure(config):
