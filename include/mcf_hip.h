@@ -191,7 +191,9 @@ MCF_API int mcf_engine_set_potential(mcf_engine *e, int32_t count, const int32_t
 MCF_API int mcf_engine_append_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values);
 /* append_potential with the caller's promise that every values[i] is its node's previous potential + sigma -- which is what
  * UpdatePotentials produces: one sigma per pivot (NS.cs:1187-1190).  Layouts that keep reduced costs per arc (large sparse instances)
- * then shift those by sigma directly, for short lists inside the next search's dispatch. */
+ * then shift those by sigma directly, for short lists inside the next search's dispatch.
+ * `values` may be NULL when the potentials are bound (mcf_engine_bind_potentials): the bound array already holds them, and the host
+ * driver's walk over a big subtree then writes node ids only. */
 MCF_API int mcf_engine_shift_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values, int64_t sigma);
 
 /* Optional: the caller keeps _pi anyway (the host solver does: sigma needs _pi[_vIn] and _pi[_uIn], NS.cs:1187-1190) -- bind that array

@@ -112,6 +112,15 @@ class ProblemStruct(C.Structure):
 
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+
+
+class _i64p_or_null(_i64p):
+    """int64 array or None (NULL) -- for the arguments the header marks as optional."""
+    @classmethod
+    def from_param(cls, obj):
+        return None if obj is None else _i64p.from_param(obj)
+
+
 _i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 _P = C.POINTER
@@ -130,7 +139,7 @@ SIGNATURES = {
     "mcf_engine_set_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i64p]),
     "mcf_engine_append_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i64p]),
     "mcf_engine_bind_potentials": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "mcf_engine_shift_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i64p, C.c_int64]),
+    "mcf_engine_shift_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i64p_or_null, C.c_int64]),
     "mcf_engine_reload_threshold": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mcf_engine_reload_potentials": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_engine_patch_arcs": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, _i64p]),

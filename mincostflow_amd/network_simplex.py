@@ -266,7 +266,10 @@ class NetworkSimplex:
     def replay(self, arcs, smaller_side=True, renumber_every=0.0):
         """mcf_ns_replay: the given entering arcs applied back to back (no engine): the sequential half alone, timed in get_metrics()."""
         arcs = _i32(arcs)
-        L.check(L.lib().mcf_ns_replay(self._h, arcs, arcs.shape[0], int(smaller_side), float(renumber_every))); return self
+        L.check(L.lib().mcf_ns_replay(self._h, arcs, arcs.shape[0], int(smaller_side), float(renumber_every)))
+        m = L.NsMetrics(); L.check(L.lib().mcf_ns_get_metrics(self._h, C.byref(m)))
+        self.replay_relabellings = int(m.reserved)          # how often the nodes were relabelled (mcf_ns_metrics.reserved after a replay)
+        return self
 
     def internal(self) -> dict:
         ms, cap = C.c_int32(), C.c_int32()
@@ -395,8 +398,9 @@ class PivotEngine:
         L.check(L.lib().mcf_engine_append_potential(self._h, nodes.shape[0], nodes, values))
 
     def shift_potential(self, nodes, values, sigma: int):
-        nodes, values = _i32(nodes), _i64(values)
-        L.check(L.lib().mcf_engine_shift_potential(self._h, nodes.shape[0], nodes, values, sigma))
+        """mcf_engine_shift_potential; `values` may be None when the potentials are bound (bind_potentials): the bound array holds them."""
+        nodes = _i32(nodes)
+        L.check(L.lib().mcf_engine_shift_potential(self._h, nodes.shape[0], nodes, None if values is None else _i64(values), sigma))
 
     def bind_potentials(self, pi):
         """mcf_engine_bind_potentials: `pi` (int64[node_count], C-contiguous) is read in place from now on; the caller keeps it alive and current."""

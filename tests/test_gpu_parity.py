@@ -1236,7 +1236,7 @@ def test_raw_engine_follows_a_relabelling_of_its_nodes(mode, bound, monkeypatch)
             a["pi"][nodes] += sigma
             if bound:
                 pi[nodes] += sigma
-                eng.shift_potential(nodes, pi[nodes], sigma)
+                eng.shift_potential(nodes, pi[nodes] if it % 3 else None, sigma)      # None: "the bound array holds them"
             else:
                 eng.update_potential(nodes, sigma)
             if it % 2 == 1:
@@ -1251,6 +1251,9 @@ def test_raw_engine_follows_a_relabelling_of_its_nodes(mode, bound, monkeypatch)
         assert eng.stats()["renumberings"] == 4
     with pytest.raises(M.McfError):
         eng.renumber_nodes(np.zeros(n, np.int32))          # not a permutation
+    if not bound:
+        with pytest.raises(M.McfError):
+            eng.shift_potential(np.arange(3, dtype=np.int32), None, 1)      # no values and no bound array to read them from
 
 
 @pytest.mark.gpu

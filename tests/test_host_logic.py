@@ -96,6 +96,40 @@ def test_sequential_driver_replays_identically(name):
         validate_solution(p, ns.flows(), ns.potentials())
 
 
+@pytest.mark.parametrize("name", ["netgen_8_10a", "transport_40x30", "grid_5x5"])
+@pytest.mark.parametrize("renumber_every", [0.0, 0.1, 0.5, 4.0])
+@pytest.mark.parametrize("smaller_side", [False, True])
+def test_replay_with_relabelled_nodes_and_smaller_side_walks(name, renumber_every, smaller_side):
+    """mcf_ns_replay: a recorded sequence of entering arcs through the host driver's own walk aids -- the smaller side of the tree moves, the
+    nodes are relabelled in thread order every `renumber_every` * n walked nodes (then the walks go in runs of consecutive ids) -- ends with the
+    oracle's flows, states and potentials (node ids restored, pi[root] back at 0).  No device involved."""
+    p = load(name)
+    o = O.Oracle(p, O.SEM_CSHARP, O.RULE_BEST)
+    assert o.init()
+    arcs = []
+    while True:
+        f, e = o.find_entering()
+        if not f:
+            break
+        assert o.apply_pivot(e) != O.UNBOUNDED
+        arcs.append(e)
+    assert o.finish() == O.OPTIMAL and len(arcs) > 20
+    ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
+    assert ns.begin() != M.SolverStatus.Infeasible
+    ns.replay(np.array(arcs, np.int32), smaller_side=smaller_side, renumber_every=renumber_every)
+    m = ns.get_metrics()
+    assert m["iterations"] == len(arcs)
+    assert ns.replay_relabellings == 0 if renumber_every == 0 else (ns.replay_relabellings >= 2 or renumber_every > 0.2), ns.replay_relabellings
+    it, oa = ns.internal(), o.internal_arrays()
+    assert np.array_equal(it["state"][: o.all_arc_num], oa["state"][: o.all_arc_num])
+    assert np.array_equal(it["pi"], oa["pi"])
+    assert ns.finish() == O.OPTIMAL
+    assert ns.get_total_cost() == o.total_cost
+    assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
+    with pytest.raises(M.McfError):
+        ns.replay(np.array([arcs[0]] * 2 + [10 ** 9], np.int32))          # an arc that cannot enter
+
+
 @pytest.mark.parametrize("kat", K.CSHARP_KATS, ids=[k[0] for k in K.CSHARP_KATS])
 def test_csharp_kats_through_the_host_driver(kat):
     name, d, status, cost, flows = kat
