@@ -740,8 +740,9 @@ def main():
                                       "solve_ms_each": sum(x.get_metrics()["loop_us"] for x in cs) / len(cs) / 1e3}
             del cs
         line["concurrent_solves_one_gpu"] = dict(conc[str(args.concurrent)], by_solves_in_flight=conc,
-                                                 note="one host thread and one resident grid per solve (MCF_ENGINE_SHARE_DEVICE: the small-footprint grid); three such grids fit a CU, "
-                                                      "a fourth waits for CUs until another solve ends -- a single solve is a host <-> device latency chain, so this is what the idle device buys")
+                                                 note="one host thread and one resident grid per solve (MCF_ENGINE_SHARE_DEVICE: the small-footprint grid); two such grids fit a CU (seven waves of 97 VGPRs each: "
+                                                      "four wave slots per SIMD), the workgroups of a third wait for CUs until another solve ends -- so three or four solves in flight run two at a time; "
+                                                      "a single solve is a host <-> device latency chain, so this is what the idle device buys")
     if not args.no_cpu_baseline and args.gpus == 1:
         line["cpu_baseline"] = cpu_baseline(g, rule, args.cpu_seconds)
         if rule != M.PivotRule.BlockSearch:

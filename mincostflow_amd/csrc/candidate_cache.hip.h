@@ -262,7 +262,7 @@ int cand_collect(mcf_engine *e, uint32_t at)
             _mm_pause();
             if (e->resident_running && (spins & 0xFFF) == 0xFFF && ((const volatile uint32_t *)e->h_exit)[0] != 0) {
                 if (((const volatile uint32_t *)e->h_exit)[0] == 4u) {
-                    (void)hipStreamSynchronize(e->stream);
+                    (void)resident_join(e, false);
                     e->resident_running = false;
                     resident_slot_release(e);
                     return mcf::fail(MCF_ERR_TIMEOUT, "the resident grid could not meet at its grid-wide barrier while a list was being applied (are its workgroups all resident?): the device arrays are undefined");
@@ -271,7 +271,7 @@ int cand_collect(mcf_engine *e, uint32_t at)
                 if (rc) return rc;
             }
             if ((++spins & 0xFFFFF) == 0) {
-                const hipError_t q = hipStreamQuery(e->stream);
+                const hipError_t q = hipStreamQuery(e->res_stream ? e->res_stream : e->stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return mcf::fail(MCF_ERR_HIP, "resident grid failed: %s", hipGetErrorString(q));
                 if (t0_wall == 0) t0_wall = mcf::now_ns();
                 else if (mcf::now_ns() - t0_wall > 20e9) return mcf::fail(MCF_ERR_TIMEOUT, "no answer from the device after 20 s (workgroup %d of %d)", g, e->res_grid);

@@ -96,6 +96,13 @@ struct mcf_engine {
     bool cfg_set = false;
     int dyn_min_block = 0, low_hits = 0, high_hits = 0;
     hipStream_t stream = nullptr;
+    // The resident grid runs on a stream of its own, of the highest priority, that exists only while the grid does.  HIP multiplexes the
+    // streams of one priority over GPU_MAX_HW_QUEUES (4) hardware queues, giving a new stream the least-used one; a queue runs its packets in
+    // order and a resident grid never leaves its queue.  With the grid on the engine's ordinary stream, a process that keeps more than a
+    // handful of engines (or other streams) alive ends up with a grid and somebody else's work -- another engine's upload, its grid, a
+    // collective -- on one queue, and that work waits until the grid leaves.  Streams of another priority have queues of their own, and
+    // streams that only exist while their grid runs are never more than the resident slots.
+    hipStream_t res_stream = nullptr;
     int32_t *d_src = nullptr, *d_tgt = nullptr;
     void *d_cost = nullptr, *d_pi = nullptr;
     int8_t *d_state = nullptr;
@@ -1108,6 +1115,7 @@ void mcf_engine_destroy(mcf_engine *e)
     (void)resident_stop(e);
     if (e->ext_pi && e->ext_pi_pinned) { if (e->stream) (void)hipStreamSynchronize(e->stream); host_unpin(e->ext_pi); }
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->res_stream) { (void)hipStreamSynchronize(e->res_stream); (void)hipStreamDestroy(e->res_stream); e->res_stream = nullptr; }
     if (e->mailbox) hsa_amd_memory_pool_free(e->mailbox);
     if (e->h_exit) (void)hipHostFree(e->h_exit);
     if (e->res_start) (void)hipEventDestroy(e->res_start);

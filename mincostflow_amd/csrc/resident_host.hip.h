@@ -77,28 +77,28 @@ void launch_resident_r(mcf_engine *e, const ResidentParams<T> &p)
     if (e->cand_on) {     // candidates: Best Eligible, register-resident tiles only
         if (e->shift_grid) {
             if constexpr (sizeof(T) == 8) {
-                if (e->cand_tiles == 2) hipExtLaunchKernelGGL((resident_cand_kernel<T, 2>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p, e->shift_base, e->max_shift_lines);
-                else hipExtLaunchKernelGGL((resident_cand_kernel<T, 4>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p, e->shift_base, e->max_shift_lines);
+                if (e->cand_tiles == 2) hipExtLaunchKernelGGL((resident_cand_kernel<T, 2>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p, e->shift_base, e->max_shift_lines);
+                else hipExtLaunchKernelGGL((resident_cand_kernel<T, 4>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p, e->shift_base, e->max_shift_lines);
             }
         }
-        else if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, true, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+        else if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, true, true>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p);
         else if (e->res_threads <= kPiRegThreads && !e->no_pireg)       // the end points' potentials stay in registers between the requests
-            hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, false, true, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
-        else hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, false, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+            hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, false, true, true>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p);
+        else hipExtLaunchKernelGGL((resident_kernel<T, MCF_RULE_BEST_ELIGIBLE, false, true, false, true>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p);
     }
-    else if (e->resident_reg && lpi) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, true, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    else if (e->resident_reg && lpi) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, true, false>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p);
     else if (e->resident_reg && e->res_threads <= kPiRegThreads && !e->no_pireg)
-        hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, false, false, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
-    else if (e->resident_reg) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, false, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
-    else if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, true, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+        hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, false, false, true>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p);
+    else if (e->resident_reg) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, true, false, false>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p);
+    else if (lpi) hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, true, false>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p);
     else {
         if constexpr (RULE == MCF_RULE_BEST_ELIGIBLE) {
             if (e->bucket_nodes > 0) {
-                hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, false, false, false, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+                hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, false, false, false, true>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p);
                 return;
             }
         }
-        hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, false, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+        hipExtLaunchKernelGGL((resident_kernel<T, RULE, OPT, false, false, false>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p);
     }
 }
 
@@ -108,13 +108,13 @@ void launch_resident_rc_r(mcf_engine *e, const ResidentRcParams &p)
     const dim3 grid(e->res_grid), block(e->res_threads);
     if constexpr (RULE == MCF_RULE_BEST_ELIGIBLE) {
         if (e->cand_on) {          // the candidate cache's grid: every search publishes each group's smallest few, not only the best
-            if (e->rc_lds) hipExtLaunchKernelGGL((resident_rc_kernel<RULE, OPT, true, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
-            else hipExtLaunchKernelGGL((resident_rc_kernel<RULE, OPT, false, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+            if (e->rc_lds) hipExtLaunchKernelGGL((resident_rc_kernel<RULE, OPT, true, true>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p);
+            else hipExtLaunchKernelGGL((resident_rc_kernel<RULE, OPT, false, true>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p);
             return;
         }
     }
-    if (e->rc_lds) hipExtLaunchKernelGGL((resident_rc_kernel<RULE, OPT, true>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
-    else hipExtLaunchKernelGGL((resident_rc_kernel<RULE, OPT, false>), grid, block, 0, e->stream, e->res_start, e->res_stop, 0, p);
+    if (e->rc_lds) hipExtLaunchKernelGGL((resident_rc_kernel<RULE, OPT, true>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p);
+    else hipExtLaunchKernelGGL((resident_rc_kernel<RULE, OPT, false>), grid, block, 0, e->res_stream, e->res_start, e->res_stop, 0, p);
 }
 
 int launch_resident_rc(mcf_engine *e, uint32_t start_seq)
@@ -127,7 +127,7 @@ int launch_resident_rc(mcf_engine *e, uint32_t start_seq)
     p.max_pi = e->patch_capacity; p.max_st = e->mailbox_max_st; p.poll_replicas = e->poll_replicas; p.poll_sleep = e->poll_sleep;
     p.src = e->d_src; p.tgt = e->d_tgt; p.cost = e->d_cost; p.n_nodes = e->d.node_count;
     p.host_pi = e->d_ext_pi; p.barrier = e->d_barrier;
-    if (e->d_barrier) HIP_TRY(hipMemsetAsync(e->d_barrier, 0, 64, e->stream));
+    if (e->d_barrier) HIP_TRY(hipMemsetAsync(e->d_barrier, 0, 64, e->res_stream));
     switch (e->d.rule) {
     case MCF_RULE_BEST_ELIGIBLE: launch_resident_rc_r<MCF_RULE_BEST_ELIGIBLE, false>(e, p); break;
     case MCF_RULE_FIRST_ELIGIBLE: launch_resident_rc_r<MCF_RULE_FIRST_ELIGIBLE, false>(e, p); break;
@@ -199,6 +199,13 @@ int resident_start(mcf_engine *e, uint32_t start_seq)
         }
     }
     for (int i = 0; i < 16; ++i) ((volatile uint32_t *)e->h_exit)[i] = 0;
+    // whatever the engine's own stream still carries (uploads, a flush) is what the grid reads when it starts
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (!e->res_stream) {
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&e->res_stream, hipStreamNonBlocking, greatest));
+    }
     int rc = e->rc_mode ? launch_resident_rc(e, start_seq) : (e->d.int_width == 32 ? launch_resident<int32_t>(e, start_seq) : launch_resident<int64_t>(e, start_seq));
     if (rc) return rc;
     e->resident_running = true;
@@ -339,6 +346,20 @@ bool cand_records_ready(const mcf_engine *e, int g);
 int resident_stop(mcf_engine *e);
 void resident_stream(mcf_engine *e);
 
+// the grid has been told to leave (or left by itself): wait for it, give its stream (and with it the hardware queue) back
+int resident_join(mcf_engine *e, bool harvest = true);
+void resident_harvest(mcf_engine *e);
+int resident_join(mcf_engine *e, bool harvest)
+{
+    if (!e->res_stream) return MCF_OK;
+    const hipError_t r = hipStreamSynchronize(e->res_stream);
+    if (r == hipSuccess && harvest) resident_harvest(e);          // (the launch's events, before their stream goes)
+    (void)hipStreamDestroy(e->res_stream);
+    e->res_stream = nullptr;
+    if (r != hipSuccess) return mcf::fail(MCF_ERR_HIP, "the resident grid ended with: %s", hipGetErrorString(r));
+    return MCF_OK;
+}
+
 // statistics of a resident launch that has ended (the grid wrote them into the exit record before it left)
 void resident_harvest(mcf_engine *e)
 {
@@ -376,10 +397,9 @@ int resident_stop(mcf_engine *e)
     if (e->seq == 0) e->seq = 1;
     if (e->shift_grid) shift_post(e, e->seq, 1u, false);
     else resident_post(e, e->seq, 1u, false);
-    HIP_TRY(hipStreamSynchronize(e->stream));       // bounded: the grid leaves on quit, or by itself after kResidentIdleTicks
+    { const int rcj = resident_join(e); if (rcj) return rcj; }       // bounded: the grid leaves on quit, or by itself after kResidentIdleTicks; counts what the launch served
     e->resident_running = false;
     e->stream_lines = 0;
-    resident_harvest(e);
     resident_slot_release(e);
     if (e->shift_grid) return device_sync_from_mirrors(e);
     return MCF_OK;
@@ -389,9 +409,8 @@ int resident_stop(mcf_engine *e)
 // finds the request in the mailbox (start_seq = the previous request)
 int resident_restart(mcf_engine *e)
 {
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    { const int rcj = resident_join(e); if (rcj) return rcj; }
     e->resident_running = false;
-    resident_harvest(e);
     if (e->shift_grid) {
         // that grid's registers are gone and the arrays in memory are not what it had: write them again from the host's mirrors (they are
         // at least as new as the request in flight, which is all a candidate list needs -- see cand_decide), and put the request there
@@ -431,7 +450,7 @@ int collect(mcf_engine *e, int grid, Key *out)
             _mm_pause();
             if (e->resident_running && (spins & 0xFFF) == 0xFFF && ((const volatile uint32_t *)e->h_exit)[0] != 0) {
                 if (((const volatile uint32_t *)e->h_exit)[0] == 4u) {
-                    (void)hipStreamSynchronize(e->stream);
+                    (void)resident_join(e, false);
                     e->resident_running = false;
                     resident_slot_release(e);
                     return mcf::fail(MCF_ERR_TIMEOUT, "the resident grid could not meet at its grid-wide barrier while a list was being applied (are its workgroups all resident?): the device arrays are undefined");
@@ -440,7 +459,7 @@ int collect(mcf_engine *e, int grid, Key *out)
                 if (rc) return rc;
             }
             if ((++spins & 0xFFFFF) == 0) {
-                const hipError_t q = hipStreamQuery(e->stream);
+                const hipError_t q = hipStreamQuery(e->resident_running && e->res_stream ? e->res_stream : e->stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return mcf::fail(MCF_ERR_HIP, "scan dispatch failed: %s", hipGetErrorString(q));
                 if (t0_wall == 0) t0_wall = mcf::now_ns();
                 else if (mcf::now_ns() - t0_wall > 20e9) return mcf::fail(MCF_ERR_TIMEOUT, "no answer from the device after 20 s (workgroup %d of %d)", g, grid);
