@@ -2,6 +2,8 @@
 Bit-exact: this is integer work.  Run with `pytest -m gpu` on an MI355X."""
 import ctypes as C
 
+import time
+
 import numpy as np
 import pytest
 
@@ -381,6 +383,31 @@ def test_sharded_solve_through_the_rccl_exchange(layout, monkeypatch):
         assert e["resident"] == 1 and e["comm_ranks"] == 1 and e["resident_requests"] > 0
         assert e["candidates"] == (1 if rule == O.RULE_BEST else 0) and (rule != O.RULE_BEST or e["host_decided"] > 0)
         assert e["rc_layout"] == (1 if layout == "rc" else 0)
+
+
+def test_engines_kept_alive_do_not_share_a_hardware_queue_with_a_resident_grid():
+    """HIP spreads the streams of one priority over four hardware queues and a resident grid never leaves its queue: with a handful of engines
+    alive in the process, a grid on its engine's ordinary stream ended up on one queue with another engine's work -- the collective of a sharded
+    solve then waited for the grid's idle timeout at every pivot (33 ms per pivot in a bench run that kept its timed solvers alive).  Grids run
+    on a stream of their own priority that lives only as long as the grid; the collective has another."""
+    g = M.netgen_like(7, 20_000, 60_000, 100, 100)
+    idle = []
+    for k in range(6):             # engines that have searched, are parked and stay alive (their ordinary streams keep their queues)
+        ns = M.NetworkSimplex.from_problem(g).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).set_pivot_limit(50)
+        assert ns.solve() == M.SolverStatus.NotSolved
+        idle.append(ns)
+    ref = M.NetworkSimplex.from_problem(g).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).set_pivot_limit(400).record_trace(400)
+    ref.solve()
+    ns = M.NetworkSimplex.from_problem(g).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).set_pivot_limit(400).record_trace(400)
+    ns.set_sharding(M.comm_unique_id(), 0, 1).prepare()
+    t0 = time.perf_counter()
+    ns.solve()
+    dt = time.perf_counter() - t0
+    e = ns.get_metrics()["engine"]
+    assert e["resident"] == 1 and e["comm_ranks"] == 1
+    assert np.array_equal(ns.trace(), ref.trace())
+    assert dt < 4.0, f"{dt:.2f} s for 400 pivots through the collective: is it waiting behind a resident grid?"       # 10 - 20 ms when not (13 s when it was)
+    del idle
 
 
 def test_pivot_limit_stops_early():
