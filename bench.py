@@ -541,6 +541,21 @@ def main():
     if args.sharded_pivots < 0:
         args.sharded_pivots = 5000 if world > 1 else 2000      # one rank: the same legs with a world of 1 (the code paths on this box, not a scaling figure)
 
+    # Extra leg, BEFORE this process touches the GPU: K independent solves with the CUs partitioned per solve (mcf_ns_set_device_share: every
+    # solver's grid gets 256 / K workgroups, i.e. CUs of its own).  In a process of its own: K resident grids need K hardware queues and
+    # GPU_MAX_HW_QUEUES is read when HIP starts (this process keeps HIP's default); and first, because every hardware queue this process
+    # opens later -- idle or not -- is one more for the GPU's scheduler to rotate the child's resident grids against (measured: 550 - 590 k
+    # pivots/s with eight solves when run after the other legs, 770 - 930 k alone on the device).
+    partitioned = None
+    if args.concurrent > 1 and args.gpus == 1 and args.workload == "config3":
+        try:
+            import subprocess
+            pr = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "gpu_concurrent.py"), "split", "4", "8", "--json"],
+                                capture_output=True, text=True, timeout=300, env=dict(os.environ, GPU_MAX_HW_QUEUES="16"))
+            partitioned = json.loads(pr.stdout.strip().splitlines()[-1]) if pr.returncode == 0 and pr.stdout.strip() else {"error": (pr.stderr or "no output")[-300:]}
+        except Exception as ex:          # the extra leg must not cost the line
+            partitioned = {"error": repr(ex)[:300]}
+
     import torch
     import mincostflow_amd as M
     if M.device_count() < 1:
@@ -739,7 +754,12 @@ def main():
             conc[str(k_in_flight)] = {"solves_in_flight": k_in_flight, "pivots_per_s": pv / dt, "seconds": dt,
                                       "solve_ms_each": sum(x.get_metrics()["loop_us"] for x in cs) / len(cs) / 1e3}
             del cs
-        line["concurrent_solves_one_gpu"] = dict(conc[str(args.concurrent)], by_solves_in_flight=conc,
+        part = partitioned
+        if isinstance(part, dict):
+            for v in part.values():
+                if isinstance(v, dict) and "pivots_of_each_solve" in v:
+                    v["first_solve_has_the_timed_solves_pivot_count"] = v["pivots_of_each_solve"][0] == mets[0]["iterations"]      # (solver 0 has the headline instance, the others other seeds)
+        line["concurrent_solves_one_gpu"] = dict(conc[str(args.concurrent)], by_solves_in_flight=conc, cus_partitioned_per_solve=part,
                                                  note="one host thread and one resident grid per solve (MCF_ENGINE_SHARE_DEVICE: the small-footprint grid); two such grids fit a CU (seven waves of 97 VGPRs each: "
                                                       "four wave slots per SIMD), the workgroups of a third wait for CUs until another solve ends -- so three or four solves in flight run two at a time; "
                                                       "a single solve is a host <-> device latency chain, so this is what the idle device buys")

@@ -389,6 +389,13 @@ MCF_API int mcf_ns_set_auto_configuration(mcf_ns *s, int32_t enable);
 /* device-side options that have no counterpart in the reference */
 MCF_API int mcf_ns_set_device(mcf_ns *s, int32_t device, int32_t int_width /* 32, 64, 0 = narrowest that is safe */,
                               int32_t block_size /* 0 = reference default */, int32_t engine_flags);
+/* Several independent solvers of one process on one device (one host thread each): every solver's resident grid gets
+ * `resident_workgroups` workgroups -- 256 / K for K solvers -- so that the grids sit on compute units of their own (a workgroup of
+ * these grids fills a CU) instead of competing for the same ones; 0 = the whole device (default).  An instance whose arcs no longer
+ * fit the registers of so few workgroups keeps reduced costs per arc (the layout of the large instances); the pivots are the same
+ * either way.  A process runs at most GPU_MAX_HW_QUEUES (HIP's variable, default 4; read when HIP starts) resident grids per device:
+ * set it to K or more before the first HIP call, further solvers serve their searches with one dispatch each. */
+MCF_API int mcf_ns_set_device_share(mcf_ns *s, int32_t resident_workgroups);
 /* shard the arc scan over `world` ranks exchanging over RCCL (every rank runs the same host loop) */
 MCF_API int mcf_ns_set_sharding(mcf_ns *s, const uint8_t nccl_id[128], int32_t rank, int32_t world);
 

@@ -192,6 +192,7 @@ SIGNATURES = {
     "mcf_ns_enable_optimizations": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_ns_set_auto_configuration": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_ns_set_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "mcf_ns_set_device_share": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_ns_set_sharding": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32]),
     "mcf_ns_set_sharding_host": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]),
     "mcf_ns_set_shard_group": (C.c_int, [C.c_void_p, C.c_int32, _i32p]),

@@ -88,6 +88,7 @@ struct mcf_ns {
         int64_t n[32] = {0}, nodes[32] = {0};
         double walk[32] = {0}, wait[32] = {0}, rest[32] = {0};
     } dbg;
+    int resident_workgroups = 0;      // mcf_ns_set_device_share: workgroups of this solver's resident grid (0 = the whole device)
     int moved_sent = 0;               // how many of them the engine already has (handed over during the walk)
     bool moved_without_values = false;// the walk wrote no moved_val (run walk: the engines read the bound _pi where they need a value)
     int engine_rc = 0;                // first error of an engine call made from inside a pivot
@@ -928,6 +929,13 @@ int mcf_ns_set_device(mcf_ns *s, int32_t device, int32_t int_width, int32_t bloc
     s->device = device; s->int_width = int_width; s->block_size = block_size; s->engine_flags = engine_flags;
     return MCF_OK;
 }
+int mcf_ns_set_device_share(mcf_ns *s, int32_t resident_workgroups)
+{
+    if (!s || resident_workgroups < 0 || resident_workgroups > 256 || (resident_workgroups > 0 && resident_workgroups < 8))
+        return mcf::fail(MCF_ERR_INVALID, "mcf_ns_set_device_share: 0 (the whole device) or 8 .. 256 workgroups");
+    s->resident_workgroups = resident_workgroups;
+    return MCF_OK;
+}
 int mcf_ns_set_sharding(mcf_ns *s, const uint8_t id[128], int32_t rank, int32_t world)
 {
     if (!s || !id || world < 1 || rank < 0 || rank >= world) return mcf::fail(MCF_ERR_INVALID, "mcf_ns_set_sharding: bad arguments");
@@ -1110,6 +1118,13 @@ int mcf_ns_prepare(mcf_ns *s)
         if (s->shard_mode != mcf_ns::kWhole) {
             rc = mcf_shard_range(s->search_arcs, s->shard_mode == mcf_ns::kGroup ? r : s->rank, s->world, &dr.shard_begin, &dr.shard_end);
             if (rc) return rc;
+        }
+        // mcf_ns_set_device_share: several independent solvers of one process on one device, each with a grid of that many workgroups
+        // (256 / K: every grid gets CUs of its own; an instance whose arcs no longer fit the registers of so few workgroups keeps reduced
+        // costs per arc instead, section 3.8 of DESIGN.md)
+        if (s->shard_mode == mcf_ns::kWhole && dr.resident_workgroups == 0) {
+            dr.resident_workgroups = s->resident_workgroups;
+            if (const char *u = getenv("MCF_NS_RESIDENT_WORKGROUPS")) { const int v = atoi(u); if (v >= 8 && v <= 256) dr.resident_workgroups = v; }      // (measurement aid)
         }
         if (s->shard_mode == mcf_ns::kRccl && dr.resident_workgroups == 0) {
             // the collective's kernel needs room beside the resident grid: leave one CU per XCD alone (mcf_engine_comm_init checks)

@@ -186,6 +186,10 @@ class NetworkSimplex:
     def set_device(self, device=0, int_width=0, block_size=0, engine_flags=0):
         L.check(L.lib().mcf_ns_set_device(self._h, device, int_width, block_size, engine_flags)); return self
 
+    def set_device_share(self, resident_workgroups: int):
+        """mcf_ns_set_device_share: this solver's resident grid gets that many workgroups (256 / K for K solvers in flight on one device)."""
+        L.check(L.lib().mcf_ns_set_device_share(self._h, resident_workgroups)); return self
+
     def set_sharding(self, nccl_id: np.ndarray, rank: int, world: int):
         L.check(L.lib().mcf_ns_set_sharding(self._h, np.ascontiguousarray(nccl_id, np.uint8), rank, world)); return self
 

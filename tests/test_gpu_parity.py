@@ -410,6 +410,30 @@ def test_engines_kept_alive_do_not_share_a_hardware_queue_with_a_resident_grid()
     del idle
 
 
+def test_solvers_that_share_a_device_by_workgroups_take_the_same_pivots():
+    """mcf_ns_set_device_share: K solvers in flight on one device, each with a resident grid of 256 / K workgroups on CUs of its own.  With so few
+    workgroups the arcs of an instance this size no longer fit the registers and the engine keeps reduced costs per arc instead -- same pivots.
+    (This process runs with HIP's default of four hardware queues: four grids are resident, and that is what the test asks for.)"""
+    import threading
+    g = M.netgen_like(13502460, 30_000, 100_000, 170, 170)
+    ref = M.NetworkSimplex.from_problem(g).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).record_trace(1 << 18)
+    assert ref.solve() == M.SolverStatus.Optimal
+    want = ref.trace().copy()
+    del ref
+    K = 4
+    cs = [M.NetworkSimplex.from_problem(g).set_pivot_rule(M.PivotRule.BestEligible).enable_optimized_pivot(True).set_device_share(256 // K).record_trace(1 << 18).prepare()
+          for _ in range(K)]
+    th = [threading.Thread(target=c.solve) for c in cs]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for c in cs:
+        assert c.status == M.SolverStatus.Optimal and np.array_equal(c.trace(), want)
+        e = c.get_metrics()["engine"]
+        assert e["resident"] == 1 and e["scan_workgroups"] == 256 // K and c.check_reduced_costs() == 0
+    with pytest.raises(M.McfError):
+        cs[0].set_device_share(3)
+
+
 def test_pivot_limit_stops_early():
     p = load("netgen_8_10a")
     ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply).set_pivot_limit(100)
