@@ -26,7 +26,13 @@ for K in K_LIST:
     for rep in range(2):
         cs = [mk(g) for g in gs]
         t0 = time.perf_counter()
-        th = [threading.Thread(target=c.solve) for c in cs]
+        def run(c, k):
+            # MCF_CONC_PIN=<first cpu>: solver k's host thread stays on cpu <first cpu> + k (sched_setaffinity with pid 0 binds the calling thread)
+            if os.environ.get("MCF_CONC_PIN"):
+                try: os.sched_setaffinity(0, {int(os.environ["MCF_CONC_PIN"]) + k})
+                except OSError: pass
+            c.solve()
+        th = [threading.Thread(target=run, args=(c, k)) for k, c in enumerate(cs)]
         [t.start() for t in th]; [t.join() for t in th]
         dt = time.perf_counter() - t0
         ms = [c.get_metrics() for c in cs]
