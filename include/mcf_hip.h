@@ -195,6 +195,12 @@ MCF_API int mcf_engine_append_potential(mcf_engine *e, int32_t count, const int3
  * `values` may be NULL when the potentials are bound (mcf_engine_bind_potentials): the bound array already holds them, and the host
  * driver's walk over a big subtree then writes node ids only. */
 MCF_API int mcf_engine_shift_potential(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values, int64_t sigma);
+/* The same list as RUNS of consecutive node ids: nodes first[r] .. first[r] + length[r] - 1 for every r, all moved by sigma; bound
+ * potentials only (the runs carry no values).  For hosts whose node ids follow the thread order (mcf_engine_renumber_nodes): the subtree
+ * of UpdatePotentials is then a few hundred runs instead of tens of thousands of nodes, the walk writes one pair per run, and the
+ * register-resident candidate grid takes the pairs as they are.  May be called several times per pivot like append_potential (the runs of
+ * one pivot must not overlap); engines without a use for runs expand them into the node list. */
+MCF_API int mcf_engine_shift_potential_runs(mcf_engine *e, int32_t n_runs, const int32_t *first, const int32_t *length, int64_t sigma);
 
 /* Optional: the caller keeps _pi anyway (the host solver does: sigma needs _pi[_vIn] and _pi[_uIn], NS.cs:1187-1190) -- bind that array
  * (int64[node_count], must outlive the binding; NULL unbinds) and the engine reads potentials from it instead of keeping a copy of its

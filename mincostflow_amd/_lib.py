@@ -140,6 +140,7 @@ SIGNATURES = {
     "mcf_engine_append_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i64p]),
     "mcf_engine_bind_potentials": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mcf_engine_shift_potential": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i64p_or_null, C.c_int64]),
+    "mcf_engine_shift_potential_runs": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.c_int64]),
     "mcf_engine_reload_threshold": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mcf_engine_reload_potentials": (C.c_int, [C.c_void_p, C.c_int32]),
     "mcf_engine_patch_arcs": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, _i64p]),

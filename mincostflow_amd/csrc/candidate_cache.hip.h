@@ -54,8 +54,60 @@ inline void cand_note_arc(mcf_engine *e, int a)
 }
 // Long lists (a big subtree): nothing will be evaluated here -- the device searches next, and a list of its epoch or later makes the
 // touched nodes' stamps irrelevant (cand_decide) -- so the list is taken over as it is, without a look at its nodes.
+constexpr int kShiftRunsPerLine = 7;        // {first, length} pairs per shift line (the shift grid's range-encoded lines)
+constexpr int kShiftRunMax = 256;           // nodes per pair: a longer run comes as several (a thread of the grid sets one pair's bits)
+
+// a big list that came as runs, as node ids after all (for the paths that read ids): the first blind_count entries of pend_node
+inline void cand_materialise_blind(mcf_engine *e)
+{
+    if (!e->blind_lazy) return;
+    e->blind_lazy = false;
+    std::vector<int32_t> ids;
+    ids.reserve(e->blind_count);
+    for (size_t r = 0; r + 1 < e->blind_runs.size(); r += 2)
+        for (uint32_t k = 0; k < e->blind_runs[r + 1]; ++k) ids.push_back((int32_t)(e->blind_runs[r] + k));
+    e->blind_runs.clear();
+    e->pend_node.insert(e->pend_node.begin(), ids.begin(), ids.end());
+    e->pend_val.insert(e->pend_val.begin(), ids.size(), 0);
+    if (!e->shift_grid) { const int64_t *pi = cand_pi(e); for (size_t i = 0; i < ids.size(); ++i) e->pend_val[i] = pi[ids[i]]; }
+}
+
+int resident_stop(mcf_engine *e);
+// mcf_engine_shift_potential_runs on the shift grid: the runs are the list (one shift for all of it, bound potentials)
+inline int cand_note_runs_blind(mcf_engine *e, int32_t n_runs, const int32_t *first, const int32_t *length, int64_t total, bool continuation)
+{
+    e->pivot_overflow = true;
+    if (e->blind_count == 0) { e->blind_epoch = e->cand_now; e->blind_sets = 0; }
+    if (!continuation) {
+        e->blind_sets += 1;
+        if (e->blind_sets > 1 && e->stream_lines > 0) { const int rc = resident_stop(e); if (rc) return rc; }
+    }
+    if (e->blind_count > 0 && !e->blind_lazy) {
+        // ids are there already (another call brought them): one form per list -- these runs become ids too
+        for (int r = 0; r < n_runs; ++r) for (int k = 0; k < length[r]; ++k) e->pend_node.push_back(first[r] + k);
+        e->pend_val.resize(e->pend_node.size(), 0);
+        e->blind_count = e->pend_node.size();
+    } else {
+        e->blind_lazy = true;
+        for (int r = 0; r < n_runs; ++r)
+            for (int32_t at = 0; at < length[r]; at += kShiftRunMax) {
+                e->blind_runs.push_back((uint32_t)(first[r] + at));
+                e->blind_runs.push_back((uint32_t)std::min<int32_t>(kShiftRunMax, length[r] - at));
+            }
+        e->blind_count += (size_t)total;
+    }
+    if (e->async_posted && cand_records_ready(e, 0)) { const int rc = cand_collect(e, e->async_at); if (rc) return rc; }
+    shift_stream(e);
+    return MCF_OK;
+}
+
 inline int cand_note_nodes_blind(mcf_engine *e, int32_t count, const int32_t *nodes, const int64_t *values, bool continuation)
 {
+    if (e->blind_lazy) {
+        // runs are there already: lines of them may have travelled in their own format, which the ids that follow cannot continue
+        if (e->shift_streamed > 0) { const int rc = resident_stop(e); if (rc) return rc; }
+        cand_materialise_blind(e);
+    }
     e->pivot_overflow = true;
     if (e->blind_count == 0) { e->blind_epoch = e->cand_now; e->blind_sets = 0; }
     if (!continuation) {
@@ -234,7 +286,7 @@ int cand_build_patches(mcf_engine *e)
     for (size_t i = 0; i < e->pend_arc.size(); ++i) e->pend_state[i] = e->h_state[e->pend_arc[i]];
     e->sync_nodes.clear();
     e->sync_arcs.clear();
-    e->blind_count = 0;
+    blind_clear(e);
     e->rc_sync.clear();
     e->rc_shift_unknown = false;
     return MCF_OK;
@@ -316,7 +368,7 @@ int cand_post_rc(mcf_engine *e)
     if (reload) {
         e->pend_node.clear(); e->pend_val.clear();
         e->sync_nodes.clear(); e->rc_sync.clear(); e->rc_shift_unknown = false;
-        e->blind_count = 0;
+        blind_clear(e);
         e->reload_pi = false;
     }
     const size_t n_b = e->blind_count, n_s = e->rc_sync.size();
@@ -332,7 +384,7 @@ int cand_post_rc(mcf_engine *e)
         e->pend_state.resize(e->pend_arc.size());
         for (size_t i = 0; i < e->pend_arc.size(); ++i) e->pend_state[i] = e->h_state[e->pend_arc[i]];
         e->sync_nodes.clear(); e->sync_arcs.clear(); e->rc_sync.clear();
-        e->blind_count = 0;
+        blind_clear(e);
     } else {
         if (int rcb = cand_build_patches(e)) return rcb;        // {node, current value} lists
         int rc = resident_stop(e);
@@ -367,15 +419,16 @@ int device_sync_from_mirrors(mcf_engine *e)
     e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
     e->pend_shift = false;
     e->sync_nodes.clear(); e->sync_arcs.clear(); e->rc_sync.clear(); e->rc_shift_unknown = false;
-    e->blind_count = 0; e->blind_sets = 0;
+    blind_clear(e); e->blind_sets = 0;
     e->shift_streamed = 0;
+    e->reload_pi = false;              // the whole array has just been copied
     e->st.mirror_uploads += 1;
     return MCF_OK;
 }
 
 // header (+ entry and shift lines when with_patches) of request `seq`; the value entries are pend_node / pend_val [val_lo, end), the shift
 // list pend_node [0, n_shift)
-void shift_post_request(mcf_engine *e, uint32_t seq, uint32_t cmd, size_t val_lo, size_t n_shift, int64_t sigma, bool with_patches)
+void shift_post_request(mcf_engine *e, uint32_t seq, uint32_t cmd, size_t val_lo, size_t n_shift, int64_t sigma, bool with_patches, bool runs = false)
 {
     alignas(16) uint32_t line[16], line1[16];
     const int n_val = with_patches ? (int)(e->pend_node.size() - val_lo) : 0, n_st = with_patches ? (int)e->pend_arc.size() : 0;
@@ -400,10 +453,15 @@ void shift_post_request(mcf_engine *e, uint32_t seq, uint32_t cmd, size_t val_lo
         else mailbox_write_line(e->mailbox + kMailboxTail + 16 * (size_t)(l - 1), line);
     }
     if (with_patches) {
-        const int total = (int)((n_shift + kShiftNodesPerLine - 1) / kShiftNodesPerLine);
+        // the shift list: n_shift node ids, or (runs) n_shift {first, length} pairs out of blind_runs
+        const int per_line = runs ? kShiftRunsPerLine : kShiftNodesPerLine;
+        const int total = (int)((n_shift + per_line - 1) / per_line);
         for (int l = e->shift_streamed; l < total; ++l) {
             memset(line, 0, sizeof(line));
-            for (int k = 0; k < kShiftNodesPerLine && (size_t)l * kShiftNodesPerLine + k < n_shift; ++k) line[k] = (uint32_t)e->pend_node[(size_t)l * kShiftNodesPerLine + k];
+            for (int k = 0; k < per_line && (size_t)l * per_line + k < n_shift; ++k) {
+                if (runs) { line[2 * k] = e->blind_runs[2 * ((size_t)l * per_line + k)]; line[2 * k + 1] = e->blind_runs[2 * ((size_t)l * per_line + k) + 1]; }
+                else line[k] = (uint32_t)e->pend_node[(size_t)l * kShiftNodesPerLine + k];
+            }
             line[15] = seq;
             mailbox_write_line(e->mailbox + e->shift_base + 16 * (size_t)l, line);
         }
@@ -414,6 +472,7 @@ void shift_post_request(mcf_engine *e, uint32_t seq, uint32_t cmd, size_t val_lo
     line[1] = cmd;
     line[2] = (uint32_t)n_val;
     line[3] = with_patches ? (uint32_t)n_shift : 0u;
+    line[4] = with_patches && runs ? 1u : 0u;      // the shift list is {first, length} pairs
     line[5] = (uint32_t)n_st;
     for (int k = 0; k < n_st && k < 2; ++k) { line[6 + 2 * k] = (uint32_t)e->pend_arc[k]; line[7 + 2 * k] = (uint32_t)e->pend_state[k]; }
     if (n_val > 0) {
@@ -447,13 +506,15 @@ void shift_stream(mcf_engine *e)
 {
     if (e->async_posted || e->blind_epoch != e->cand_now || e->blind_sets > 1 || !e->pend_shift) return;
     if (!e->resident_running || e->in_flight != mcf_engine::kNoSearch) return;
-    const int complete = (int)(e->blind_count / kShiftNodesPerLine);
+    const bool runs = e->blind_lazy;
+    const int complete = runs ? (int)(e->blind_runs.size() / 2 / kShiftRunsPerLine) : (int)(e->blind_count / kShiftNodesPerLine);
     if (complete - e->shift_streamed < shift_stream_min_lines() || complete > e->max_shift_lines) return;
     uint32_t next_seq = e->seq + 1;
     if (next_seq == 0) next_seq = 1;
     alignas(16) uint32_t line[16];
     for (int l = e->shift_streamed; l < complete; ++l) {
-        for (int k = 0; k < kShiftNodesPerLine; ++k) line[k] = (uint32_t)e->pend_node[(size_t)l * kShiftNodesPerLine + k];
+        if (runs) { memcpy(line, e->blind_runs.data() + (size_t)l * 2 * kShiftRunsPerLine, sizeof(uint32_t) * 2 * kShiftRunsPerLine); line[14] = 0u; }
+        else for (int k = 0; k < kShiftNodesPerLine; ++k) line[k] = (uint32_t)e->pend_node[(size_t)l * kShiftNodesPerLine + k];
         line[15] = next_seq;
         mailbox_write_line(e->mailbox + e->shift_base + 16 * (size_t)l, line);
     }
@@ -461,7 +522,7 @@ void shift_stream(mcf_engine *e)
     if (e->stream_sub == 0) e->stream_sub = 1;
     memset(line, 0, sizeof(line));
     line[0] = next_seq;
-    line[1] = 2u;
+    line[1] = runs ? 4u : 2u;                      // "shift lines in place": node ids / {first, length} pairs
     line[3] = (uint32_t)complete;
     line[4] = e->stream_sub;
     line[15] = next_seq;
@@ -480,10 +541,42 @@ int cand_post_shift(mcf_engine *e)
         const int rc = resident_start(e, e->seq);
         if (rc) return rc;
     }
+    if (e->reload_pi) {
+        // mcf_engine_reload_potentials: the grid reads the bound array when it serves the request (cmd 3), so every potential change noted up to
+        // now is part of it -- the lists are dropped, the state writes travel with the request.  (A grid that has just been started read the
+        // arrays the host wrote from its mirrors: nothing to reload, resident_start cleared the flag.)
+        if (!e->d_ext_pi || e->shift_streamed > 0 || (int64_t)e->sync_arcs.size() > (int64_t)e->mailbox_max_st) {
+            int rc = resident_stop(e);              // device_sync_from_mirrors: nothing is left to tell
+            if (!rc) rc = resident_start(e, e->seq);
+            if (rc) return rc;
+        }
+    }
+    if (e->reload_pi) {
+        e->pend_node.clear(); e->pend_val.clear();
+        e->sync_nodes.clear();
+        blind_clear(e);
+        e->pend_arc.assign(e->sync_arcs.begin(), e->sync_arcs.end());
+        e->pend_state.resize(e->pend_arc.size());
+        for (size_t i = 0; i < e->pend_arc.size(); ++i) e->pend_state[i] = e->h_state[e->pend_arc[i]];
+        e->prev_seq = e->seq;
+        e->seq += 1;
+        if (e->seq == 0) e->seq = 1;
+        shift_post_request(e, e->seq, 3u, 0, 0, 0, true);
+        e->st.rc_reloads_in_grid += 1;
+        e->pend_arc.clear(); e->pend_state.clear();
+        e->sync_arcs.clear();
+        e->stream_lines = 0;
+        e->reload_pi = false;
+        e->posted_at = e->cand_now;
+        e->st.arcs_scanned += e->end - e->begin;
+        return MCF_OK;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         const size_t n_b = e->blind_count, n_s = e->sync_nodes.size();
         const bool blind_current = n_b == 0 || (e->blind_epoch == e->cand_now && e->blind_sets <= 1);
-        const bool as_shift = n_b > 0 && blind_current && e->pend_shift && n_b <= (size_t)e->max_shift_lines * kShiftNodesPerLine;
+        const size_t n_pairs = e->blind_lazy ? e->blind_runs.size() / 2 : 0;
+        const bool as_shift = n_b > 0 && blind_current && e->pend_shift &&
+                              (e->blind_lazy ? n_pairs <= (size_t)e->max_shift_lines * kShiftRunsPerLine : n_b <= (size_t)e->max_shift_lines * kShiftNodesPerLine);
         const bool fits = (int64_t)(as_shift ? n_s : n_b + n_s) <= (int64_t)e->patch_capacity && (int64_t)e->sync_arcs.size() <= (int64_t)e->mailbox_max_st;
         if ((!as_shift && e->shift_streamed > 0) || !fits) {
             // lines of a list that is no shift list any more have travelled, or the request would not fit: bring the device up to date wholesale
@@ -493,23 +586,25 @@ int cand_post_shift(mcf_engine *e)
             continue;
         }
         const int64_t *pi = cand_pi(e);
-        const size_t val_lo = as_shift ? n_b : 0;
+        const bool runs = as_shift && e->blind_lazy;          // the pairs travel as they are; pend_node then holds the value entries only
+        if (!as_shift) cand_materialise_blind(e);              // ... as ids otherwise
+        const size_t base = runs ? 0 : n_b, val_lo = as_shift ? base : 0;
         if (!as_shift) for (size_t i = 0; i < n_b; ++i) e->pend_val[i] = pi[e->pend_node[i]];      // current values (a node named twice carries the same one)
-        e->pend_node.resize(n_b + n_s);
-        e->pend_val.resize(n_b + n_s);
-        for (size_t i = 0; i < n_s; ++i) { e->pend_node[n_b + i] = e->sync_nodes[i]; e->pend_val[n_b + i] = pi[e->sync_nodes[i]]; }
+        e->pend_node.resize(base + n_s);
+        e->pend_val.resize(base + n_s);
+        for (size_t i = 0; i < n_s; ++i) { e->pend_node[base + i] = e->sync_nodes[i]; e->pend_val[base + i] = pi[e->sync_nodes[i]]; }
         e->pend_arc.assign(e->sync_arcs.begin(), e->sync_arcs.end());
         e->pend_state.resize(e->pend_arc.size());
         for (size_t i = 0; i < e->pend_arc.size(); ++i) e->pend_state[i] = e->h_state[e->pend_arc[i]];
         e->prev_seq = e->seq;
         e->seq += 1;
         if (e->seq == 0) e->seq = 1;
-        shift_post_request(e, e->seq, 0u, val_lo, as_shift ? n_b : 0, e->pend_sigma, true);
+        shift_post_request(e, e->seq, 0u, val_lo, as_shift ? (runs ? n_pairs : n_b) : 0, e->pend_sigma, true, runs);
         if (!e->pend_node.empty() || !e->pend_arc.empty()) e->st.inline_updates += 1;
         if (as_shift) e->st.shift_lists += 1;
         e->pend_node.clear(); e->pend_val.clear(); e->pend_arc.clear(); e->pend_state.clear();
         e->sync_nodes.clear(); e->sync_arcs.clear();
-        e->blind_count = 0;
+        blind_clear(e);
         e->stream_lines = 0;
         e->posted_at = e->cand_now;
         e->st.arcs_scanned += e->end - e->begin;

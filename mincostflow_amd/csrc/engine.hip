@@ -180,6 +180,7 @@ struct mcf_engine {
     bool has_slot = false;         // this engine's grid occupies one of the device's resident slots (resident_slot_acquire)
     // the candidate cache's register-resident grid that is patched straight from the request (resident_cand_kernel): the one big subtree of
     // a pivot travels as bare node ids + sigma, the arrays in memory are only read when the grid starts (and written by the host when it stops)
+    int shift_reload_min = 0;          // shift grid: nodes from which a walk is announced as a reload of the bound potentials (0 = never)
     bool shift_grid = false;
     uint32_t shift_base = 0;       // dword offset of the shift lines in the mailbox
     int max_shift_lines = 0;
@@ -226,6 +227,11 @@ struct mcf_engine {
     std::vector<int32_t> sync_nodes, sync_arcs;   // changed since the device last heard from us (values are read from the mirrors when the request is built)
     size_t blind_count = 0;                       // the same for big subtrees: node lists taken over wholesale, with their values -- they are the
                                                   // first blind_count entries of pend_node / pend_val already (and may have started travelling)
+    // A big list may also come as RUNS of consecutive node ids (mcf_engine_shift_potential_runs: after a relabelling in thread order a subtree
+    // is a few hundred runs, not tens of thousands of nodes).  Then blind_runs holds {first, length} pairs, blind_count the nodes they cover, and
+    // pend_node has NO entries for them until somebody needs ids (cand_materialise_blind) -- the shift grid takes the pairs as they are.
+    std::vector<uint32_t> blind_runs;
+    bool blind_lazy = false;
     uint32_t blind_epoch = 0;                     // epoch of the first of those lists
     int blind_sets = 0;                           // lists in there that did not come as the continuation of another one
     bool force_device_search = false;             // mcf_engine_bench_search: every search goes to the device (the cache would answer without one)
@@ -260,6 +266,16 @@ struct mcf_engine {
     void *d_flush = nullptr;
     size_t flush_bytes = 0;
 };
+
+namespace {
+// no big list is pending any more (in either form)
+inline void blind_clear(mcf_engine *e)
+{
+    e->blind_count = 0;
+    e->blind_runs.clear();
+    e->blind_lazy = false;
+}
+}  // namespace
 
 namespace {
 
@@ -1047,6 +1063,16 @@ int mcf_engine_create(mcf_engine **out, const mcf_engine_desc *desc)
                     if (t > kCandThreads) e->shift_grid = false;       // cannot happen: resident_reg caps the arcs at 1 M
                     else e->res_threads = (int)t;
                 }
+                if (e->shift_grid) {
+                    // walks of this many nodes and more travel as "reload the bound potentials" (cmd 3: copy + grid-wide barrier + gather, inside the
+                    // grid) instead of as a node list: the host's walk then writes nothing but its own potentials.  MCF_HIP_SHIFT_RELOAD=N (0 = never)
+                    // Measured on config 3 (tools/gpu_walk_variants.py): the reload costs 40 - 44 us in the grid (800 KB over PCIe, the barrier, the
+                    // gather) against 13 - 15 for a list that travelled during the walk, and saves the walk its list only before the first
+                    // relabelling -- from 32768 nodes on it wins (246 against 240 - 245 k pivots/s), from 8192 on it does not (243 k).
+                    e->shift_reload_min = 32768;
+                    if (const char *u = getenv("MCF_HIP_SHIFT_RELOAD")) { const int v = atoi(u); e->shift_reload_min = v > 0 ? v : 0; }
+                    if (e->shift_reload_min > 0 && hipMalloc((void **)&e->d_barrier, 64) != hipSuccess) { e->d_barrier = nullptr; (void)hipGetLastError(); }
+                }
             }
         }
     }
@@ -1222,7 +1248,7 @@ int mcf_engine_upload(mcf_engine *e, const int32_t *source, const int32_t *targe
         e->snap_at = 0;
         e->heap_gap = 0;
         e->async_posted = false;
-        e->sync_nodes.clear(); e->sync_arcs.clear(); e->blind_count = 0;
+        e->sync_nodes.clear(); e->sync_arcs.clear(); blind_clear(e);
         e->rc_sync.clear(); e->rc_shift_unknown = false;
         cand_reset(e);
         e->heap_gap = 0;
@@ -1430,7 +1456,7 @@ int mcf_engine_bind_potentials(mcf_engine *e, const int64_t *pi)
     // RC layout, 64-bit potentials: the array is made known to HIP so that a reload (mcf_engine_reload_potentials) is one asynchronous copy.
     // Several engines of one solver bind the same array: the first registers it, the others find it registered.
     e->d_ext_pi = nullptr;
-    if (pi && e->rc_mode && e->d.int_width == 64) {
+    if (pi && (e->rc_mode || (e->shift_grid && e->shift_reload_min > 0)) && e->d.int_width == 64) {
         (void)hipSetDevice(e->d.device);
         e->ext_pi_pinned = host_pin(pi, sizeof(int64_t) * (size_t)e->d.node_count);
         if (e->ext_pi_pinned && e->resident_ok && !(getenv("MCF_HIP_RC_INGRID_RELOAD") && getenv("MCF_HIP_RC_INGRID_RELOAD")[0] == '0')) {
@@ -1446,6 +1472,7 @@ int mcf_engine_reload_threshold(mcf_engine *e, int32_t *min_nodes)
 {
     if (!e || !min_nodes) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_reload_threshold: null argument");
     *min_nodes = (e->rc_mode && e->ext_pi && e->ext_pi_pinned && e->rc_recompute_above < INT32_MAX) ? e->rc_recompute_above + 1 : 0;
+    if (e->shift_grid && e->ext_pi && e->ext_pi_pinned && e->d_ext_pi && e->shift_reload_min > 0) *min_nodes = e->shift_reload_min;
     return MCF_OK;
 }
 
@@ -1453,7 +1480,7 @@ int mcf_engine_reload_potentials(mcf_engine *e, int32_t changed_nodes)
 {
     if (!e || changed_nodes < 0) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_reload_potentials: bad arguments");
     if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
-    if (!(e->rc_mode && e->ext_pi && e->ext_pi_pinned)) return mcf::fail(MCF_ERR_STATE, "mcf_engine_reload_potentials: this engine takes node lists (see mcf_engine_reload_threshold)");
+    if (!((e->rc_mode || (e->shift_grid && e->d_ext_pi)) && e->ext_pi && e->ext_pi_pinned)) return mcf::fail(MCF_ERR_STATE, "mcf_engine_reload_potentials: this engine takes node lists (see mcf_engine_reload_threshold)");
     if (e->in_flight == mcf_engine::kResidentSearch || e->in_flight == mcf_engine::kCandSearch || e->in_flight == mcf_engine::kDispatchSearch) {
         // the array must not change while a search reads from it: the caller is between two searches by contract; an answered one may still wait to be fetched
         return mcf::fail(MCF_ERR_STATE, "mcf_engine_reload_potentials: a search is in flight");
@@ -1467,7 +1494,7 @@ int mcf_engine_reload_potentials(mcf_engine *e, int32_t changed_nodes)
         e->sync_nodes.clear();
         e->rc_sync.clear();
         e->rc_shift_unknown = false;
-        e->blind_count = 0;
+        blind_clear(e);
     }
     e->reload_pi = true;
     e->mirror_valid = false;
@@ -1488,6 +1515,36 @@ int mcf_engine_shift_potential(mcf_engine *e, int32_t count, const int32_t *node
     if (rc) return rc;
     if (count > 0 && !e->cand_on) { e->pend_shift = same; e->pend_sigma = sigma; }
     return MCF_OK;
+}
+
+int mcf_engine_shift_potential_runs(mcf_engine *e, int32_t n_runs, const int32_t *first, const int32_t *length, int64_t sigma)
+{
+    if (!e || n_runs < 0 || (n_runs && (!first || !length))) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_shift_potential_runs: bad arguments");
+    if (!e->uploaded) return mcf::fail(MCF_ERR_STATE, "mcf_engine_upload has not been called");
+    if (n_runs && !e->ext_pi) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_shift_potential_runs: the potentials must be bound (mcf_engine_bind_potentials): the runs carry no values");
+    int64_t total = 0;
+    for (int r = 0; r < n_runs; ++r) {
+        if (first[r] < 0 || length[r] <= 0 || (int64_t)first[r] + length[r] > e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "run %d: nodes [%d, %d + %d) outside the graph", r, first[r], first[r], length[r]);
+        total += length[r];
+    }
+    if (total > e->d.node_count) return mcf::fail(MCF_ERR_INVALID, "%lld nodes in a graph of %d: the runs of one pivot must not overlap", (long long)total, e->d.node_count);
+    if (total == 0) return MCF_OK;
+    if (e->cand_on && e->shift_grid && e->d.int_width == 64 && (total > e->cand_max_nodes || e->pivot_overflow)) {
+        // the register-resident candidate grid takes the pairs as they are (seven to a line instead of fifteen node ids)
+        const bool first_list = e->blind_count == 0;
+        e->pend_shift = first_list || (e->pend_shift && e->pend_sigma == sigma);
+        e->pend_sigma = sigma;
+        const bool continuation = e->pivot_overflow && e->blind_count > 0 && e->blind_epoch == e->cand_now;
+        const int rc = cand_note_runs_blind(e, n_runs, first, length, total, continuation);
+        if (rc) return rc;
+        e->st.potential_nodes += total;
+        return MCF_OK;
+    }
+    // every other engine: the same list as node ids
+    std::vector<int32_t> ids;
+    ids.reserve((size_t)total);
+    for (int r = 0; r < n_runs; ++r) for (int k = 0; k < length[r]; ++k) ids.push_back(first[r] + k);
+    return mcf_engine_shift_potential(e, (int32_t)total, ids.data(), nullptr, sigma);
 }
 
 int mcf_engine_patch_arcs(mcf_engine *e, int32_t count, const int32_t *arcs, const int32_t *source, const int32_t *target, const int64_t *cost)
@@ -1598,7 +1655,7 @@ int mcf_engine_renumber_nodes(mcf_engine *e, const int32_t *new_of)
     if (e->ext_pi) {
         e->pend_node.clear(); e->pend_val.clear(); e->pend_shift = false;
         e->reload_pi = false;
-        if (e->cand_on) { e->sync_nodes.clear(); e->rc_sync.clear(); e->rc_shift_unknown = false; e->blind_count = 0; }
+        if (e->cand_on) { e->sync_nodes.clear(); e->rc_sync.clear(); e->rc_shift_unknown = false; blind_clear(e); }
     }
     rc = flush_pending(e);
     if (rc) return rc;

@@ -586,6 +586,8 @@ struct ResidentParams {
     int32_t max_pi;             // potential patches the mailbox can hold
     int32_t max_st;             // state patches it can hold
     int32_t poll_replicas, poll_sleep;
+    const int64_t *host_pi;     // resident_cand_kernel: the caller's bound potentials in mapped host memory (cmd 3 reloads from them), or null
+    uint32_t *barrier;          // ... and the arrival counter of its grid-wide barrier (zero at launch)
 };
 
 __device__ __forceinline__ void resident_exit(uint32_t *exit_word, uint32_t code, uint32_t served, uint64_t scan_ticks)
@@ -990,11 +992,15 @@ __global__ __launch_bounds__(PIREG ? kPiRegThreads : kResidentThreads) void resi
 //     the shift: a value is read by the host when the request is built).  Few: compared directly; many: rounds of up to kCandRoundLines
 //     lines through a hash table in LDS (node -> value) that every thread probes for its eight end points.
 //   * STATE WRITES {arc, state}: compared against the thread's four arcs.
+//   * RELOAD (cmd 3): a walk so long that its node list would cost more than it is worth names no nodes: the host only moves its own
+//     potentials, the workgroups copy the bound array (mapped host memory; each its slice, coalesced, over PCIe) into the device array, meet
+//     at a grid-wide barrier and every thread gathers its end points' potentials again.  The one place where this grid touches memory.
 // The arrays in memory are only read when the grid starts: the host, whose mirrors are authoritative in candidate mode, writes them again
 // before every launch (resident_start) -- so a grid that left on its idle timeout comes back with current values and the request it finds
 // waiting is re-posted without patches.
 constexpr int kShiftBits = 131072;                // nodes the exact bitmap covers (16 KB of LDS)
 constexpr int kShiftNodesPerLine = 15;
+constexpr int kShiftPairsPerLine = 7;             // ... or seven {first id, length} pairs: runs of consecutive ids (the host relabels the nodes in thread order)
 constexpr int kCandLines = 512;                   // staging: line 0 + 511 lines (32 KB)
 constexpr int kCandRoundLines = 480;              // value-entry lines per hash round: 2400 entries in ...
 constexpr int kCandHash = 4096;                   // ... this many slots
@@ -1002,10 +1008,11 @@ constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;
 constexpr int kCandCompare = 3;                   // value entries beyond the header's that are matched by direct comparison (~40 instructions each)
 
 // Mailbox of this grid.  Poll unit (replicated): line 0 = header, line 1 = first entry line.
-//   line 0   [0] seq [1] cmd (0 scan, 1 quit, 2 shift lines in place) [2] n_val [3] scan: n_shift nodes / cmd 2: shift lines in place so far
+//   line 0   [0] seq [1] cmd (0 scan, 1 quit, 2 shift lines in place, 3 reload the potentials, then scan) [2] n_val [3] scan: n_shift nodes / cmd 2: shift lines in place so far
 //            [4] cmd 2: post counter [5] n_st [6..9] state writes 0, 1 {arc, state} [10..12] value entry 0 {node, lo, hi} [13..14] sigma [15] seq
 //   entry lines (tail, from kMailboxTail): five {a, b, c} each: value entries 1.., then state writes 2..; [15] = seq
-//   shift lines (from shift_base): fifteen node ids each; [15] = seq of the scan request they belong to
+//   shift lines (from shift_base): fifteen node ids each, or (scan: line 0 [4] == 1; in-place posts: cmd 4 instead of 2) seven {first id,
+//            length} pairs; [15] = seq of the scan request they belong to
 // TILES register tiles of four arcs per thread (tile t of a thread lies gridDim * blockDim * 4 arcs behind tile t - 1), at most kCandThreads
 // threads: four waves, one per SIMD of the CU.  A wave instruction takes four cycles and two waves on one SIMD take turns, so the reductions of
 // seven waves of 448 threads (one tile each) ran at half the rate of these four.
@@ -1050,6 +1057,30 @@ __global__ __launch_bounds__(kCandThreads) void resident_cand_kernel(const Resid
     uint32_t last = p.start_seq, served = 0, last_sub = 0, shifted_for = p.start_seq;
     int shift_done = 0;                                   // shift lines of the coming scan request whose bits are set
     bool bits_set = false;
+    uint32_t reloaded_for = p.start_seq, barriers = 0;    // a request's reload happens once (a retry after a torn line must not meet the others at the barrier again)
+    // grid-wide barrier (all workgroups are resident: one per CU); false when it gave up -- every spin of this kernel is bounded
+    auto grid_barrier = [&]() -> bool {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        barriers += 1;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(p.barrier, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t want = barriers * gridDim.x;
+            const uint64_t t_bar = __builtin_amdgcn_s_memrealtime();
+            uint32_t gave_up = 0u;
+            while (__hip_atomic_load(p.barrier, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t_bar > 8ull * p.idle_ticks) { gave_up = 1u; break; }
+            }
+            s_timeout = gave_up ? 3u : 0u;
+        }
+        __syncthreads();
+        if (s_timeout == 3u) return false;
+        // what the other XCDs wrote through to memory may still sit in this CU's L1 / this XCD's L2 in its old form: forget it
+        if (tid < 64) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        return true;
+    };
     uint64_t scan_ticks = 0;
     uint64_t ph_shift = 0, ph_values = 0, ph_scan = 0, n_shift_req = 0;       // workgroup 0's clock by phase (exit record words 4..11)
     const uint64_t born_rt = __builtin_amdgcn_s_memrealtime(), born_clk = __builtin_amdgcn_s_memtime();
@@ -1099,7 +1130,7 @@ __global__ __launch_bounds__(kCandThreads) void resident_cand_kernel(const Resid
                 if (tid < 8) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x) : "v"(my_unit + tid * 4) : "memory");
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)::"memory");
                 const uint32_t seq0 = lane_u32(x[0], 0), tag0 = lane_u32(x[3], 3), cmd0 = lane_u32(x[1], 0), sub0 = lane_u32(x[0], 1);
-                if (seq0 != last && tag0 == seq0 && (cmd0 != 2u || sub0 != last_sub)) { flag = 1u; break; }
+                if (seq0 != last && tag0 == seq0 && ((cmd0 != 2u && cmd0 != 4u) || sub0 != last_sub)) { flag = 1u; break; }
                 if (__builtin_amdgcn_s_memrealtime() - idle_since > p.idle_ticks) { flag = 2u; break; }
                 for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
             }
@@ -1111,10 +1142,13 @@ __global__ __launch_bounds__(kCandThreads) void resident_cand_kernel(const Resid
         int n_val = (int)lm[2], n_st = (int)lm[5];
         n_val = n_val < 0 ? 0 : (n_val > p.max_pi ? p.max_pi : n_val);
         n_st = n_st < 0 ? 0 : (n_st > p.max_st ? p.max_st : n_st);
-        const bool apply_only = cmd == 2u;
-        int n_shift = apply_only ? 0 : (int)lm[3];
-        n_shift = n_shift < 0 ? 0 : (n_shift > max_shift_lines * kShiftNodesPerLine ? max_shift_lines * kShiftNodesPerLine : n_shift);
-        int shift_lines = apply_only ? (int)lm[3] : (n_shift + kShiftNodesPerLine - 1) / kShiftNodesPerLine;
+        const bool apply_only = cmd == 2u || cmd == 4u;
+        // the shift list comes as node ids (15 per line) or as {first, length} pairs (7 per line: runs of consecutive ids)
+        const bool ranges = apply_only ? cmd == 4u : lm[4] == 1u;
+        const int per_line = ranges ? kShiftPairsPerLine : kShiftNodesPerLine;
+        int n_shift = apply_only ? 0 : (int)lm[3];                      // entries: nodes or pairs
+        n_shift = n_shift < 0 ? 0 : (n_shift > max_shift_lines * per_line ? max_shift_lines * per_line : n_shift);
+        int shift_lines = apply_only ? (int)lm[3] : (n_shift + per_line - 1) / per_line;
         shift_lines = shift_lines < 0 ? 0 : (shift_lines > max_shift_lines ? max_shift_lines : shift_lines);
         const int64_t sigma = (int64_t)(((uint64_t)lm[14] << 32) | lm[13]);
         const bool timed_out = s_timeout == 2u;
@@ -1138,6 +1172,28 @@ __global__ __launch_bounds__(kCandThreads) void resident_cand_kernel(const Resid
             return;
         }
         const uint64_t t_seen = blockIdx.x == 0 ? __builtin_amdgcn_s_memrealtime() : 0;
+        // ---- reload: every potential anew from the caller's array, my end points' potentials anew from them (NS.cs:1196-1208 moved so many
+        // nodes that the host sends no list: it only moved its own potentials)
+        if (cmd == 3u && p.host_pi && reloaded_for != seq) {
+            const int per = (p.n_nodes + (int)gridDim.x - 1) / (int)gridDim.x;
+            const int lo = (int)blockIdx.x * per, hi = lo + per < p.n_nodes ? lo + per : p.n_nodes;
+            // agent scope: written through to memory, where the workgroups of the other XCDs (each with an L2 of its own) will find it
+            for (int i = lo + tid; i < hi; i += nt) __hip_atomic_store(p.pi + i, (T)p.host_pi[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!grid_barrier()) {
+                // the grid leaves with code 3: the host writes the arrays from its mirrors, starts it again and posts the request as a plain scan
+                if (tid == 0) resident_exit(p.exit_word, 3u, served, scan_ticks);
+                return;
+            }
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) gather_tile<T>(mine[t], p.pi, ps[t], pt[t]);
+            if (bits_set) {                                   // lines of a list that is part of the array now
+                for (int i = tid; i < kShiftBits / 32; i += nt) bitmap[i] = 0u;
+                bits_set = false;
+                __syncthreads();
+            }
+            shift_done = 0;
+            reloaded_for = seq;
+        }
         // ---- what has to be fetched: shift lines not seen yet, entry lines (value entries 1.., then state writes 2..) unless the one line
         // there is came with the poll
         const int extra_val = n_val > 1 ? n_val - 1 : 0, extra_st = n_st > 2 ? n_st - 2 : 0, entries = apply_only ? 0 : extra_val + extra_st;
@@ -1146,6 +1202,26 @@ __global__ __launch_bounds__(kCandThreads) void resident_cand_kernel(const Resid
         const int need_v = inline_entries ? 0 : lines;
         // the nodes of `chunk` staged shift lines (staged from lm line `off`; `first` = index of the first of them in the list): set their bits
         auto set_bits = [&](int off, int first, int chunk) {
+            if (ranges) {
+                // one thread per pair: a pair covers at most 256 ids = nine words of the bitmap
+                const int left = n_shift - first * kShiftPairsPerLine;
+                const int pairs_here = apply_only ? chunk * kShiftPairsPerLine : (left < chunk * kShiftPairsPerLine ? left : chunk * kShiftPairsPerLine);
+                for (int i = tid; i < pairs_here; i += nt) {
+                    const uint32_t *q = lm + kStage + (off + i / kShiftPairsPerLine) * 16 + 2 * (i % kShiftPairsPerLine);
+                    const uint32_t a = q[0];
+                    uint32_t len = q[1];
+                    if (a >= (uint32_t)kShiftBits || len == 0u) continue;
+                    if (len > (uint32_t)kShiftBits - a) len = (uint32_t)kShiftBits - a;
+                    const uint32_t z = a + len - 1u;                  // last id
+                    for (uint32_t w = a >> 5; w <= (z >> 5); ++w) {
+                        uint32_t mask = 0xFFFFFFFFu;
+                        if (w == (a >> 5)) mask &= 0xFFFFFFFFu << (a & 31u);
+                        if (w == (z >> 5)) mask &= 0xFFFFFFFFu >> (31u - (z & 31u));
+                        atomicOr(&bitmap[w], mask);
+                    }
+                }
+                return;
+            }
             const int left = n_shift - first * kShiftNodesPerLine;
             const int nodes_here = apply_only ? chunk * kShiftNodesPerLine : (left < chunk * kShiftNodesPerLine ? left : chunk * kShiftNodesPerLine);
             // A subtree's nodes come as runs of consecutive ids (the host relabels the nodes in thread order), and 32 consecutive ids share a

@@ -53,6 +53,7 @@ struct mcf_ns {
     int64_t walked_since_renumber = 0, jumps_since_renumber = 0, renumbers = 0;
     bool allow_renumber = false;
     bool fused_cycle_search = true;   // find_join + find_leaving in one climb (MCF_NS_FUSED_CYCLE=0: two climbs, as the reference does it)
+    bool use_runs = true;             // ... and hand the big ones over as runs of consecutive ids (MCF_NS_RUNS=0: as nodes)
     bool seq_walk = true;             // after the first relabelling the big walks go in runs of consecutive ids (MCF_NS_SEQWALK=0: keep the hinted walk)
     double renumber_every = 128.0;    // relabel when the walks since the last relabelling covered this many times the node count
     double renumber_ticks = 0, renumber_last_ticks = 0, renumber_last_at = 0;
@@ -91,6 +92,11 @@ struct mcf_ns {
     int resident_workgroups = 0;      // mcf_ns_set_device_share: workgroups of this solver's resident grid (0 = the whole device)
     int moved_sent = 0;               // how many of them the engine already has (handed over during the walk)
     bool moved_without_values = false;// the walk wrote no moved_val (run walk: the engines read the bound _pi where they need a value)
+    // a big walk after a relabelling writes RUNS of consecutive ids instead of nodes (mcf_engine_shift_potential_runs): run_first / run_len,
+    // runs_n of them, runs_sent already handed over
+    bool moved_as_runs = false;
+    int runs_n = 0, runs_sent = 0;
+    mcf::hvec<int32_t> run_first, run_len;
     int engine_rc = 0;                // first error of an engine call made from inside a pivot
     double piece_ticks = 0;           // time inside the hand-over calls made during the walks (part of the potential-update bucket)
     bool hand_over = false;           // a device engine is attached: state writes and potential pieces go to it as they arise
@@ -128,6 +134,12 @@ int engines_append_potential(mcf_ns *s, int32_t count, const int32_t *nodes, con
 {
     int rc = mcf_engine_shift_potential(s->engine, count, nodes, values, s->sigma); // the potentials are replicated on every shard
     for (size_t i = 0; i < s->peers.size() && !rc; ++i) rc = mcf_engine_shift_potential(s->peers[i], count, nodes, values, s->sigma);
+    return rc;
+}
+int engines_shift_runs(mcf_ns *s, int32_t n_runs, const int32_t *first, const int32_t *length)
+{
+    int rc = mcf_engine_shift_potential_runs(s->engine, n_runs, first, length, s->sigma);
+    for (size_t i = 0; i < s->peers.size() && !rc; ++i) rc = mcf_engine_shift_potential_runs(s->peers[i], n_runs, first, length, s->sigma);
     return rc;
 }
 int engines_reload_potentials(mcf_ns *s, int32_t changed)
@@ -411,6 +423,7 @@ void rehang_subtree(mcf_ns *s)
 //    prefetches the lines it will need kWalkAhead steps from now; a stale hint costs a useless prefetch, nothing else.
 // The order of the resulting list is irrelevant to the engine (final values).
 constexpr int kWalkAhead = 8, kWalkHintMin = 48;
+constexpr int kRunsMin = 512;      // walks of this many nodes and more hand over runs of consecutive ids (after a relabelling)
 int walk_piece()                   // a big walk hands its nodes to the engine in pieces of this size (2048; mcf_engine_append_potential);
 {
     static const int v = [] { int x = 2048; if (const char *u = getenv("MCF_NS_WALK_PIECE")) { const int y = atoi(u); if (y >= 64 && y <= (1 << 20)) x = y; } return x; }();
@@ -486,6 +499,7 @@ void shift_potentials(mcf_ns *s)
     s->moved_n = count;
     s->moved_as_reload = false;
     s->moved_without_values = false;
+    s->moved_as_runs = false;
     if (s->reload_min > 0 && count >= s->reload_min) {
         // A walk this long is cheaper for the engines as "reload _pi" than as a list (mcf_engine_reload_potentials): nothing is written down,
         // the walk only moves the potentials.  The hints need the node kWalkAhead steps back: a ring of that many.
@@ -536,6 +550,41 @@ void shift_potentials(mcf_ns *s)
         // After a relabelling in thread order the successor of node a is a + 1 almost everywhere: walk in RUNS.  Inside a run the next
         // address does not depend on the loaded successor (the exit test is a predicted branch, not a data dependency), so the loads of
         // consecutive nodes overlap and the hardware prefetcher sees a linear stream; a jump costs one unpredicted miss.
+        if (s->use_runs && count >= kRunsMin) {
+            // RUNS: one {first id, length} pair per run instead of the nodes -- the walk stores nothing per node but the potential itself, and the
+            // engines get a list an order of magnitude shorter (the register-resident candidate grid takes the pairs as they are)
+            int32_t *const rf = s->run_first.data(), *const rl = s->run_len.data();
+            int i = 0, a = first, nr = 0;
+            int64_t jumps = 0;
+            s->moved_as_runs = true;
+            s->runs_sent = 0;
+            while (i < count) {
+                const int stop = s->hand_over && count - (s->moved_sent + piece) >= piece / 2 ? std::max(i, s->moved_sent + piece) : count;
+                while (i < stop) {
+                    const int start = a;
+                    int len = 0;
+                    for (;;) {
+                        pi[a] += sigma;
+                        const int nx = nxt[a];
+                        ++i; ++len;
+                        if (nx != a + 1) { a = nx; ++jumps; break; }
+                        ++a;
+                        if (i >= stop) break;
+                    }
+                    rf[nr] = start; rl[nr] = len; ++nr;
+                }
+                if (i < count) {
+                    const double tp = ticks();
+                    if (!s->engine_rc) s->engine_rc = engines_shift_runs(s, nr - s->runs_sent, rf + s->runs_sent, rl + s->runs_sent);
+                    s->piece_ticks += ticks() - tp;
+                    s->moved_sent = i;
+                    s->runs_sent = nr;
+                }
+            }
+            s->runs_n = nr;
+            s->jumps_since_renumber += jumps;
+            return;
+        }
         // The engines have _pi bound (mcf_engine_bind_potentials): the list goes without values.
         int i = 0, a = first;
         int64_t jumps = 0;
@@ -833,6 +882,7 @@ int mcf_ns_create(mcf_ns **out, int32_t node_count, int32_t arc_count, const int
     s->state.assign(A, 0);
     s->supply.assign(N, 0); s->pi.assign(N, 0);
     s->par.assign(N, -1); s->par_arc.assign(N, -1); s->nxt.assign(N, 0); s->prv.assign(N, 0); s->moved.assign(N, 0); s->moved_val.assign(N, 0); s->follow.assign(N, 0);
+    s->run_first.assign(N, 0); s->run_len.assign(N, 0);
     s->sub.assign(N, 0); s->fin.assign(N, 0); s->par_dir.assign(N, 0); s->scratch.assign(N + 1, 0);
     *out = s;
     return MCF_OK;
@@ -1183,6 +1233,11 @@ int mcf_ns_prepare(mcf_ns *s)
         s->renumber_every = 128.0;
         if (const char *u = getenv("MCF_NS_RENUMBER")) { const double v = atof(u); if (v > 0) { s->renumber_every = v; s->renumber_forced = true; } }
         s->seq_walk = !(getenv("MCF_NS_SEQWALK") && getenv("MCF_NS_SEQWALK")[0] == '0');
+        // runs of consecutive ids instead of node lists: for the grid that takes them as they are (every other engine would expand them again)
+        {
+            mcf_engine_stats es;
+            s->use_runs = mcf_engine_get_stats(s->engine, &es) == MCF_OK && es.shift_grid != 0 && s->peers.empty() && !(getenv("MCF_NS_RUNS") && getenv("MCF_NS_RUNS")[0] == '0');
+        }
         s->fused_cycle_search = !(getenv("MCF_NS_FUSED_CYCLE") && getenv("MCF_NS_FUSED_CYCLE")[0] == '0');
     }
     s->cands.assign((size_t)std::max(1, s->world), mcf_candidate{0, 0xFFFFFFFFu, -1, 0, 0xFFFFFFFFu, -1});
@@ -1268,6 +1323,7 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         const double t1 = ticks();
         rc = s->engine_rc;
         if (!rc && s->moved_as_reload) rc = engines_reload_potentials(s, (int32_t)s->moved_n);
+        else if (!rc && s->moved_as_runs) { if (s->runs_n > s->runs_sent) rc = engines_shift_runs(s, s->runs_n - s->runs_sent, s->run_first.data() + s->runs_sent, s->run_len.data() + s->runs_sent); }
         else if (!rc && s->moved_n > s->moved_sent)
             rc = engines_append_potential(s, (int32_t)(s->moved_n - s->moved_sent), s->moved.data() + s->moved_sent, s->moved_without_values ? nullptr : s->moved_val.data() + s->moved_sent);
         const double t2 = ticks();

@@ -147,6 +147,9 @@ int launch_resident(mcf_engine *e, uint32_t start_seq)
     p.slots = e->d_slots; p.orig = e->bucket_nodes > 0 ? e->d_orig : nullptr; p.mailbox = e->mailbox; p.exit_word = e->d_exit;
     p.base = e->begin; p.count_padded = e->count_padded; p.m_s = e->d.search_arc_num;
     p.start_seq = start_seq; p.idle_ticks = resident_idle_ticks(); p.n_nodes = e->d.node_count; p.max_pi = e->patch_capacity; p.max_st = e->mailbox_max_st; p.poll_replicas = e->poll_replicas; p.poll_sleep = e->poll_sleep;
+    p.host_pi = e->shift_grid && e->d_barrier ? e->d_ext_pi : nullptr;
+    p.barrier = e->d_barrier;
+    if (p.host_pi) HIP_TRY(hipMemsetAsync(e->d_barrier, 0, 64, e->res_stream));
     const bool opt = e->d.semantics == MCF_SEM_OPTIMIZED;
     switch (e->d.rule) {
     case MCF_RULE_BEST_ELIGIBLE: launch_resident_r<T, MCF_RULE_BEST_ELIGIBLE, false>(e, p); break;

@@ -406,6 +406,11 @@ class PivotEngine:
         nodes = _i32(nodes)
         L.check(L.lib().mcf_engine_shift_potential(self._h, nodes.shape[0], nodes, None if values is None else _i64(values), sigma))
 
+    def shift_potential_runs(self, first, length, sigma: int):
+        """mcf_engine_shift_potential_runs: nodes first[r] .. first[r] + length[r] - 1 for every r moved by sigma (bound potentials only)."""
+        first, length = _i32(first), _i32(length)
+        L.check(L.lib().mcf_engine_shift_potential_runs(self._h, first.shape[0], first, length, sigma))
+
     def bind_potentials(self, pi):
         """mcf_engine_bind_potentials: `pi` (int64[node_count], C-contiguous) is read in place from now on; the caller keeps it alive and current."""
         if pi is None:

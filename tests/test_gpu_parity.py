@@ -702,12 +702,14 @@ RC_MODES = [pytest.param("rc", id="rc-layout"), pytest.param("rc-resident", id="
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", RC_MODES)
+@pytest.mark.parametrize("mode", RC_MODES + [pytest.param(0, id="candidates-shift-grid")])
 def test_reload_of_the_bound_potentials_replaces_node_lists(mode, monkeypatch):
     """mcf_engine_bind_potentials + mcf_engine_reload_potentials (RC layout): after changes to a large part of the caller's array the engine is told
     'reload' instead of being handed the nodes; it copies the array by itself and computes every reduced cost again.  Mixed with ordinary lists
     and state writes, with further small lists between the reload and the search, in every RC engine mode: the oracle's answer every time."""
     flags = _mode_flags(mode, monkeypatch)
+    if mode == 0:
+        monkeypatch.setenv("MCF_HIP_SHIFT_RELOAD", "8192")       # the register-resident grid's own threshold (32768 nodes) is more than this graph has
     rng = np.random.default_rng(4711)
     m_s, n = 120_003, 25_000
     a = _random_soa(rng, m_s, n, 30, 200, extra=0)
@@ -716,7 +718,8 @@ def test_reload_of_the_bound_potentials_replaces_node_lists(mode, monkeypatch):
     assert eng.reload_threshold() == 0                      # nothing bound yet: lists only
     eng.bind_potentials(a["pi"])
     lo = eng.reload_threshold()
-    assert lo == max(1024, n // 16) + 1
+    shift_grid = mode == 0         # the register-resident candidate grid: the reload is a copy + a grid-wide barrier + a gather inside the grid
+    assert lo == (8192 if shift_grid else max(1024, n // 16) + 1)
     for it in range(40):
         f, arc, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
         assert eng.find_entering() == (f, arc, c), it
@@ -748,7 +751,7 @@ def test_reload_of_the_bound_potentials_replaces_node_lists(mode, monkeypatch):
     st = eng.stats()
     # a resident grid carries the reloads out itself (the workgroups copy the bound array, meet at a grid-wide barrier and compute their arcs'
     # reduced costs again); with one dispatch per search the array is copied and rc_init_kernel runs
-    assert st["rc_layout"] == 1 and st["rc_recomputes"] + st["rc_reloads_in_grid"] >= 25
+    assert st["rc_layout"] == (0 if shift_grid else 1) and st["shift_grid"] == (1 if shift_grid else 0) and st["rc_recomputes"] + st["rc_reloads_in_grid"] >= 25
     assert st["rc_reloads_in_grid"] >= (25 if mode != "rc" else 0) and (mode != "rc" or st["rc_reloads_in_grid"] == 0)
     assert eng.check_reduced_costs() == (0, -1)
     assert np.array_equal(eng.download_pi(), a["pi"]) and np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
@@ -771,6 +774,26 @@ def test_solve_that_reloads_the_potentials_after_long_walks(name, mode, monkeypa
     m = ns.get_metrics()
     assert m["engine"]["rc_layout"] == 1 and m["engine"]["rc_recomputes"] + m["engine"]["rc_reloads_in_grid"] > 50
     assert mode == "rc" or m["engine"]["rc_reloads_in_grid"] > 50
+
+
+@pytest.mark.gpu
+def test_shift_grid_reloads_the_potentials_inside_the_grid(monkeypatch):
+    """The register-resident candidate grid with its reload threshold lowered from 32768 to 48 nodes: every longer walk of the solve names no
+    nodes, the workgroups copy the bound _pi, meet at their grid-wide barrier and gather their end points again (cmd 3) -- the oracle's pivots,
+    flows and potentials; with relabellings in between (the bound array is permuted in place) and without."""
+    monkeypatch.setenv("MCF_HIP_SHIFT_RELOAD", "48")
+    g = M.netgen_like(7, 20_000, 60_000, 100, 100)
+    p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
+    for renumber in ("0", "0.5"):
+        monkeypatch.setenv("MCF_NS_RENUMBER", renumber)
+        o, st_o, tr_o, ns, st = _solve_both(p, O.SEM_CSHARP_OPT, O.RULE_BEST, int_width=64, flags=0)
+        assert st == st_o == O.OPTIMAL
+        assert np.array_equal(ns.trace(), tr_o), int(np.argmax(ns.trace()[: len(tr_o)] != tr_o[: len(ns.trace())]))
+        assert ns.get_total_cost() == o.total_cost
+        assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
+        e = ns.get_metrics()["engine"]
+        assert e["shift_grid"] == 1 and e["rc_reloads_in_grid"] > 50, e["rc_reloads_in_grid"]
+        assert (e["renumberings"] > 0) == (renumber != "0")
 
 
 @pytest.mark.gpu
@@ -815,6 +838,61 @@ def test_potential_lists_that_arrive_in_pieces(mode, m_s, n, monkeypatch):
         cuts = sorted(set([0, total] + [int(x) for x in rng.integers(0, total + 1, int(rng.integers(0, 5)))]))
         for lo, hi in zip(cuts[:-1], cuts[1:]):
             eng.append_potential(nodes[lo:hi], a["pi"][nodes[lo:hi]])
+    assert np.array_equal(eng.download_pi(), a["pi"])
+    assert np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+def test_potential_lists_as_runs_of_consecutive_ids(mode, monkeypatch):
+    """mcf_engine_shift_potential_runs: a pivot's list as {first id, length} pairs (bound potentials), in one call or several, runs longer than a
+    pair may cover, mixed with ordinary lists before and after in the same pivot (ids after runs, runs after ids: one form per list).  The
+    register-resident candidate grid takes the pairs as they are (range-encoded shift lines), every other engine expands them."""
+    flags = _mode_flags(mode, monkeypatch)
+    rng = np.random.default_rng(77)
+    m_s, n = 400003, 100001
+    a = _random_soa(rng, m_s, n, 3, 9)
+    eng = M.PivotEngine(n, len(a["src"]), m_s, rule=M.PivotRule.BestEligible, optimized=True, flags=flags)
+    eng.upload(a["src"], a["tgt"], a["cost"], a["state"], a["pi"])
+    with pytest.raises(M.McfError):
+        eng.shift_potential_runs([0], [5], 1)                    # nothing bound: runs carry no values
+    pi = a["pi"]
+    eng.bind_potentials(pi)
+    for it in range(14):
+        f, e, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+        f2, e2, c2 = eng.find_entering()
+        assert f2 == f and (not f or (e2, c2) == (e, c)), (it, e2, e, c2, c)
+        arcs = rng.choice(m_s, size=2, replace=False).astype(np.int32); vals = rng.integers(-1, 2, 2).astype(np.int8)
+        a["state"][arcs] = vals
+        eng.patch_state(arcs, vals)
+        R = int(rng.choice([1, 3, 40, 900, 6000]))
+        cut = np.sort(rng.choice(n, size=2 * R, replace=False))
+        first, length = cut[0::2].astype(np.int32), (cut[1::2] - cut[0::2]).astype(np.int32)       # disjoint runs [first, first + length)
+        sigma = int(rng.integers(-4, 5)) or 1
+        for lo, ln in zip(first, length):
+            pi[lo:lo + ln] += sigma
+        kind = it % 5
+        if kind == 3:                                            # a big list of ids first, the runs continue it
+            free = np.setdiff1d(np.arange(n), np.concatenate([np.arange(lo, lo + ln) for lo, ln in zip(first, length)]))
+            ids = rng.choice(free, size=700, replace=False).astype(np.int32)
+            pi[ids] += sigma
+            eng.shift_potential(ids, None, sigma)
+        pieces = sorted(set([0, R] + [int(x) for x in rng.integers(0, R + 1, int(rng.integers(0, 3)))]))
+        for lo, hi in zip(pieces[:-1], pieces[1:]):
+            eng.shift_potential_runs(first[lo:hi], length[lo:hi], sigma)
+        if kind == 1:                                            # a few nodes on top of it, named one by one
+            few = rng.choice(n, size=4, replace=False).astype(np.int32)
+            pi[few] += 7
+            eng.shift_potential(few, pi[few], 7)
+        if kind == 4:                                            # ... or a big list of ids behind the runs
+            free = np.setdiff1d(np.arange(n), np.concatenate([np.arange(lo, lo + ln) for lo, ln in zip(first, length)]))
+            ids = rng.choice(free, size=900, replace=False).astype(np.int32)
+            pi[ids] += sigma
+            eng.shift_potential(ids, None, sigma)
+    f, e, c, _ = _oracle_scan(O.RULE_BEST, True, a, m_s, 1, 0)
+    assert eng.find_entering() == (f, e, c)
+    with pytest.raises(M.McfError):
+        eng.shift_potential_runs([n - 3], [5], 1)                # runs off the end of the graph
     assert np.array_equal(eng.download_pi(), a["pi"])
     assert np.array_equal(eng.download_state()[:m_s], a["state"][:m_s])
 
