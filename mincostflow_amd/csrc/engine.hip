@@ -1448,6 +1448,8 @@ int mcf_engine_bind_potentials(mcf_engine *e, const int64_t *pi)
 {
     if (!e) return mcf::fail(MCF_ERR_INVALID, "mcf_engine_bind_potentials: null engine");
     if (e->in_flight != mcf_engine::kNoSearch) return mcf::fail(MCF_ERR_STATE, "mcf_engine_bind_potentials: a search is in flight");
+    // a running grid was launched with the old array's address among its arguments (it reloads from there): it leaves first
+    if (e->resident_running) { (void)hipSetDevice(e->d.device); const int rcs = resident_stop(e); if (rcs) return rcs; }
     if (e->ext_pi && e->ext_pi_pinned) host_unpin(e->ext_pi);
     e->ext_pi_pinned = false;
     e->reload_pi = false;
