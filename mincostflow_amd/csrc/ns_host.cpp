@@ -56,7 +56,7 @@ struct mcf_ns {
     bool use_runs = true;             // ... and hand the big ones over as runs of consecutive ids (MCF_NS_RUNS=0: as nodes)
     bool seq_walk = true;             // after the first relabelling the big walks go in runs of consecutive ids (MCF_NS_SEQWALK=0: keep the hinted walk)
     double renumber_every = 128.0;    // relabel when the walks since the last relabelling covered this many times the node count
-    double renumber_ticks = 0, renumber_last_ticks = 0, renumber_last_at = 0;
+    double renumber_ticks = 0, renumber_last_ticks = 0, renumber_last_at = 0, renumber_jump_budget = 0;
     int64_t renumber_at_pivot = 0;
     bool renumber_forced = false;     // MCF_NS_RENUMBER set: relabel at that interval whatever it costs (tests)
     int64_t sum_supply = 0, art_cost = 0;
@@ -423,6 +423,7 @@ void rehang_subtree(mcf_ns *s)
 //    prefetches the lines it will need kWalkAhead steps from now; a stale hint costs a useless prefetch, nothing else.
 // The order of the resulting list is irrelevant to the engine (final values).
 constexpr int kWalkAhead = 8, kWalkHintMin = 48;
+constexpr double kJumpNs = 24.0;   // what a step of a walk that leaves the id order costs (a mispredicted branch and a miss; measured 23 - 25 ns)
 constexpr int kRunsMin = 512;      // walks of this many nodes and more hand over runs of consecutive ids (after a relabelling)
 int walk_piece()                   // a big walk hands its nodes to the engine in pieces of this size (2048; mcf_engine_append_potential);
 {
@@ -1300,13 +1301,18 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
         ++it;
         if (it > max_iter) { s->status = MCF_INFEASIBLE; break; }                          // NS.cs:311-317
         if (s->pivot_limit && it > s->pivot_limit) { --it; limited = true; break; }
-        // ... when the walks since the last time covered renumber_every times the node count, and not more often than it pays: a relabelling
-        // costs the engines a rebuild of their per-node tables (0.3 s with 9 M arcs), so the next one waits 25 times as long as the last one took
-        // Locality is not only the walks' business: the cycle searches and the candidate cache's re-evaluation of the moved nodes' arcs chase
-        // the same ids, so a quarter of n pivots since the last time count as well.
+        // When to relabel.  The first time: when the walks have covered renumber_every times the node count, or a quarter of n pivots have passed
+        // (the cycle searches and the candidate cache's re-evaluation of the moved nodes' arcs chase the same ids).  After that the walks count
+        // their JUMPS -- the steps that leave the id order, 23 - 25 ns each, which is what a relabelling buys back -- and the next relabelling
+        // comes when the jumps since the last one have cost five times what that one took (2.9 ms with 400 k arcs, 0.3 s with 9 M: the engines
+        // rebuild their per-node tables).  Config 5, whole solve: 28.9 s with the 4 relabellings of the first policy (a fixed interval, and never
+        // before 25 times the last one's duration), 26.7 with 6, 27.9 with 12; config 3: flat between 6 and 13.  MCF_NS_RENUMBER=x forces an interval.
         if (s->dbg.on && (it % 100000) == 0) fprintf(stderr, "[ns] %lld pivots, %.2f s\n", (long long)it, (mcf::now_ns() - t_start) / 1e9);
-        if (s->allow_renumber && ((double)s->walked_since_renumber > s->renumber_every * (s->n + 1) || (!s->renumber_forced && 4 * (it - s->renumber_at_pivot) > (int64_t)s->n)) &&
-            (s->renumbers == 0 || s->renumber_forced || ticks() - s->renumber_last_at > 25.0 * s->renumber_last_ticks)) {
+        const bool relabel_now = !s->allow_renumber ? false
+            : s->renumber_forced ? (double)s->walked_since_renumber > s->renumber_every * (s->n + 1)
+            : s->renumbers == 0 ? ((double)s->walked_since_renumber > s->renumber_every * (s->n + 1) || 4 * (it - s->renumber_at_pivot) > (int64_t)s->n)
+            : (double)s->jumps_since_renumber > s->renumber_jump_budget;
+        if (relabel_now) {
             // no search in flight, nothing of a pivot half done: relabel the nodes in thread order, here and in the engines
             const double tr0 = ticks();
             std::vector<int32_t> perm;
@@ -1315,6 +1321,10 @@ int mcf_ns_solve(mcf_ns *s, int32_t *status)
             s->renumber_last_ticks = ticks() - tr0;
             s->renumber_last_at = ticks();
             s->renumber_at_pivot = it;
+            {   // jumps that cost five times this relabelling (kJumpNs each)
+                const double ns_per_tick_now = (mcf::now_ns() - t_start) / std::max(1.0, ticks() - tick_start);
+                s->renumber_jump_budget = 5.0 * s->renumber_last_ticks * ns_per_tick_now / kJumpNs;
+            }
             s->renumber_ticks += s->renumber_last_ticks;
             if (rc) break;
         }
