@@ -96,14 +96,18 @@ def test_sequential_driver_replays_identically(name):
         validate_solution(p, ns.flows(), ns.potentials())
 
 
-@pytest.mark.parametrize("name", ["netgen_8_10a", "transport_40x30", "grid_5x5"])
+@pytest.mark.parametrize("name", ["netgen_8_10a", "transport_40x30", "grid_5x5", "generated-6000"])
 @pytest.mark.parametrize("renumber_every", [0.0, 0.1, 0.5, 4.0])
 @pytest.mark.parametrize("smaller_side", [False, True])
 def test_replay_with_relabelled_nodes_and_smaller_side_walks(name, renumber_every, smaller_side):
     """mcf_ns_replay: a recorded sequence of entering arcs through the host driver's own walk aids -- the smaller side of the tree moves, the
     nodes are relabelled in thread order every `renumber_every` * n walked nodes (then the walks go in runs of consecutive ids) -- ends with the
     oracle's flows, states and potentials (node ids restored, pi[root] back at 0).  No device involved."""
-    p = load(name)
+    if name == "generated-6000":       # big enough for walks of 512 nodes and more: after a relabelling those write runs of consecutive ids, not nodes
+        g = M.netgen_like(99, 6000, 20000, 60, 60)
+        p = O.Problem(g.node_count, g.arc_count, g.source, g.target, g.lower, g.upper, g.cost, g.supply)
+    else:
+        p = load(name)
     o = O.Oracle(p, O.SEM_CSHARP, O.RULE_BEST)
     assert o.init()
     arcs = []
@@ -128,6 +132,16 @@ def test_replay_with_relabelled_nodes_and_smaller_side_walks(name, renumber_ever
     assert np.array_equal(ns.flows(), o.flow()) and np.array_equal(ns.potentials(), o.potential())
     with pytest.raises(M.McfError):
         ns.replay(np.array([arcs[0]] * 2 + [10 ** 9], np.int32))          # an arc that cannot enter
+
+
+def test_device_share_arguments():
+    """mcf_ns_set_device_share: 0 (the whole device) or 8 .. 256 workgroups; nothing else (no device needed to say so)."""
+    p = load("grid_5x5")
+    ns = M.NetworkSimplex(p.n, p.src, p.tgt).set_problem(p.lower, p.upper, p.cost, p.supply)
+    ns.set_device_share(0).set_device_share(8).set_device_share(256)
+    for bad in (-1, 3, 257):
+        with pytest.raises(M.McfError):
+            ns.set_device_share(bad)
 
 
 @pytest.mark.parametrize("kat", K.CSHARP_KATS, ids=[k[0] for k in K.CSHARP_KATS])
